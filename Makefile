@@ -1,0 +1,40 @@
+# Build recipe for the gfx950 radix-sort engine, the CPU oracle and the harness.
+#   make            -> radx_amd/lib/libradx_hip.so, oracle/libradx_oracle.so, harness/sort_test
+#   make resources  -> per-kernel VGPR/SGPR/LDS/occupancy report
+HIPCC    ?= /opt/rocm/bin/hipcc
+CC       ?= gcc
+CXX      ?= g++
+ARCH     ?= gfx950
+HIPFLAGS ?= -O3 -std=c++17 -fPIC --offload-arch=$(ARCH) -Iinclude -Wall -Wno-unused-function
+
+LIB      := radx_amd/lib/libradx_hip.so
+ORACLE   := oracle/libradx_oracle.so
+CPUSORT  := oracle/libradx_cpusort.so
+HARNESS  := harness/sort_test
+
+all: $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS)
+
+$(LIB): radx_amd/csrc/radx_hip.hip include/radx_hip.h
+	@mkdir -p radx_amd/lib
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ radx_amd/csrc/radx_hip.hip
+
+$(ORACLE): oracle/radx_oracle.c oracle/radx_oracle.h
+	$(CC) -O2 -std=c11 -fPIC -shared -Wall -Wextra -o $@ oracle/radx_oracle.c
+
+$(CPUSORT): oracle/cpu_sort.cpp
+	$(CXX) -O3 -std=c++17 -fPIC -shared -fopenmp -Wall -o $@ oracle/cpu_sort.cpp
+
+$(HARNESS): harness/sort_test.cpp $(LIB) $(CPUSORT) $(wildcard include/radx/*.hpp) include/radx_hip.h
+	$(CXX) -O2 -std=c++17 -fopenmp -Wall -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
+	    -o $@ harness/sort_test.cpp \
+	    -Lradx_amd/lib -lradx_hip -Loracle -lradx_cpusort -L/opt/rocm/lib -lamdhip64 \
+	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,'$$ORIGIN/../oracle' -Wl,-rpath,/opt/rocm/lib
+
+resources:
+	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null radx_amd/csrc/radx_hip.hip 2>&1 | \
+	    grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" | grep -v "^$$" || true
+
+clean:
+	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS)
+
+.PHONY: all clean resources

@@ -1,0 +1,149 @@
+/*
+ * radx_hip.h — C ABI of the gfx950 LSD radix-sort engine.
+ *
+ * This is the boundary the header-only C++ layer in include/radx/ binds to, and the only
+ * thing a replacement engine has to export.  Plain pointers and sizes; no C++ or torch
+ * types.  Every function returns 0 on success or the failing hipError_t value
+ * (argument errors are reported as hipErrorInvalidValue == 1); radx_hip_error_string()
+ * gives the text of the last failure on the calling thread.
+ *
+ * What each entry point replaces in the reference (paths relative to the reference tree):
+ *   radx_hip_create / radx_hip_scratch_bytes / radx_hip_destroy
+ *       radx::Radix::createInternalMemory      include/radx/radx_implement.inl:450-490
+ *       (one scratch allocation holding the histogram and prefix-scan tables) and
+ *       radx::Radix::initialize                include/radx/radx_implement.inl:391-418
+ *       (pipeline creation; here the kernels are part of the code object).
+ *   radx_hip_sort
+ *       radx::Radix::command                   include/radx/radx_implement.inl:421-447
+ *       reached through radx::Sort<T>::command include/radx/radx_internal.hpp:129-132.
+ *       Work is enqueued on the caller's stream exactly as the reference records into the
+ *       caller's command buffer; nothing has executed when the call returns.
+ *   radx_hip_pass / radx_hip_copy_tables
+ *       one iteration of the loop at radx_implement.inl:427-444 (counting, partition,
+ *       scattering: shaders-sdk/radix/{counting,partition,scattering}.comp) with the
+ *       histogram (binding 3) and prefix-sum (binding 4) tables readable afterwards.
+ *   radx_hip_generate_* / radx_hip_check_sorted / radx_hip_checksum
+ *       device-side counterparts of the harness's key generation and of the result
+ *       comparison the harness omits     src/test/sort.cpp:226-234,342-350,452-469.
+ *
+ * Ownership: the caller owns keys / swap (and vals / vals_swap); each must hold at least
+ * n elements and be 16-byte aligned.  The sorter owns only its scratch tables.  The sorted
+ * result is left in `keys` (and `vals`); the swap buffers are clobbered
+ * (shaders-sdk/radix/scattering.comp:40,143 ping-pong by pass parity, pass count even).
+ * One sort may be in flight per sorter handle; use one handle per concurrent stream.
+ */
+#ifndef RADX_HIP_H
+#define RADX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct radx_hip_sorter radx_hip_sorter;
+
+/* Digit width of one pass and the number of bins, fixed at build time. */
+#define RADX_HIP_BITS_PER_PASS 4
+#define RADX_HIP_RADICES 16
+
+/* Library version as major*10000 + minor*100 + patch. */
+int radx_hip_version(void);
+
+/* Text of the last error raised on this thread ("" when none). */
+const char* radx_hip_error_string(void);
+
+/* Bytes of device scratch a sorter for up to max_n elements of key_bytes (4 or 8) holds. */
+size_t radx_hip_scratch_bytes(uint64_t max_n, int key_bytes);
+
+/*
+ * Create a sorter on HIP device `device` for at most max_n elements.
+ * key_bytes: 4 (uint32 keys) or 8 (uint64 keys).  value_bytes: 0 (keys only) or 4
+ * (uint32 payload that travels with its key).  max_n must be < 2^32: the reference's
+ * element count is a 32-bit uniform (include/radx/radx_implement.inl:381-383).
+ */
+int radx_hip_create(int device, uint64_t max_n, int key_bytes, int value_bytes,
+                    radx_hip_sorter** out);
+
+int radx_hip_destroy(radx_hip_sorter* s);
+
+/*
+ * Enqueue a full ascending, unsigned, stable sort of n elements on `stream`
+ * (a hipStream_t passed as void*; NULL is the default stream).
+ * vals / vals_swap must be NULL for a keys-only sorter and non-NULL otherwise.
+ */
+int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals,
+                  void* vals_swap, uint64_t n, void* stream);
+
+/*
+ * As radx_hip_sort, restricted to key bits [begin_bit, end_bit).  The number of passes,
+ * ceil((end_bit-begin_bit)/4), is rounded up to an even count so the result still lands
+ * in `keys`; a padding pass sorts on a zero-width digit and is a stable copy.
+ */
+int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals,
+                       void* vals_swap, uint64_t n, int begin_bit, int end_bit, void* stream);
+
+/*
+ * Enqueue ONE pass (histogram -> scan -> scatter) reading keys_in / vals_in and writing
+ * keys_out / vals_out, on the digit of `num_bits` (1..4) bits starting at bit `bit`.
+ * The tables stay in the sorter's scratch until the next call.
+ */
+int radx_hip_pass(radx_hip_sorter* s, const void* keys_in, void* keys_out, const void* vals_in,
+                  void* vals_out, uint64_t n, int bit, int num_bits, void* stream);
+
+/*
+ * Tile geometry of the engine for n elements: keys per tile and number of tiles.
+ * Tile t covers elements [t*tile, min((t+1)*tile, n)).
+ */
+int radx_hip_geometry(const radx_hip_sorter* s, uint64_t n, uint32_t* tile_keys,
+                      uint32_t* num_tiles);
+
+/*
+ * Synchronise `stream` and copy the tables of the last pass to host memory, both laid
+ * out [RADX_HIP_RADICES][num_tiles] (digit-major):
+ *   counts[d][t]  = keys of tile t whose digit is d          (reference counts[g][r])
+ *   offsets[d][t] = first output index for digit d of tile t (reference partitions[g][r])
+ * Either pointer may be NULL.
+ */
+int radx_hip_copy_tables(radx_hip_sorter* s, uint64_t n, uint32_t* counts, uint32_t* offsets,
+                         void* stream);
+
+/*
+ * Synchronise `stream` and copy 17 uint32 to host: the start index of each digit's output run
+ * of the last pass, followed by n.  out[d+1]-out[d] = number of keys with digit d.
+ */
+int radx_hip_digit_starts(radx_hip_sorter* s, uint32_t out[17], void* stream);
+
+/*
+ * Per-kernel timing.  When enabled, every launch made through this sorter is bracketed by
+ * HIP events on the launch stream; radx_hip_kernel_times synchronises those events and
+ * returns, per kernel kind (0 histogram, 1 scan, 2 scatter), the summed milliseconds and
+ * the number of launches since the last reset.
+ */
+int radx_hip_profile(radx_hip_sorter* s, int enable);
+int radx_hip_kernel_times(radx_hip_sorter* s, double ms[3], uint64_t launches[3]);
+
+/* ---- harness utilities (device side of src/test/sort.cpp's generation and checking) ---- */
+
+/* keys[i] = H(i ^ seed), H = the 32-bit integer hash of src/test/sort.cpp:226-234. */
+int radx_hip_generate_u32(void* keys, uint64_t n, uint32_t seed, void* stream);
+/* keys[i] = (uint64)H(i ^ seed) << 32 | H(~i ^ seed);  vals[i] = i (vals may be NULL). */
+int radx_hip_generate_u64(void* keys, void* vals, uint64_t n, uint32_t seed, void* stream);
+
+/*
+ * Synchronous.  *violations = number of i in [1,n) with keys[i-1] > keys[i]
+ * (for key_bytes 8 with vals != NULL also counts equal keys whose payloads decrease,
+ * i.e. stability violations when payload = original index).
+ */
+int radx_hip_check_sorted(const void* keys, const void* vals, uint64_t n, int key_bytes,
+                          uint64_t* violations, void* stream);
+
+/* Synchronous.  out[0] = sum of keys mod 2^64, out[1] = xor of keys, out[2] = sum of H(key). */
+int radx_hip_checksum(const void* keys, uint64_t n, int key_bytes, uint64_t out[3],
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RADX_HIP_H */

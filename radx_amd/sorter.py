@@ -1,0 +1,143 @@
+"""Thin Python driver over the C ABI: hands torch device buffers and the current HIP stream
+to libradx_hip.so.  torch is used for device memory and streams only; every byte of sorting
+work happens in the HIP kernels behind include/radx_hip.h.
+
+The call sequence mirrors the reference's host API (include/radx/radx_internal.hpp:104-148):
+a Sorter owns the scratch tables (Sort<Radix>::initialize -> Radix::createInternalMemory) and
+sort() enqueues the pass loop on a stream (Sort::command -> Radix::command); the sorted
+result is left in `keys`, `swap` is clobbered.
+"""
+import ctypes
+
+import numpy as np
+
+from . import capi
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else ctypes.c_void_p(None)
+
+
+def _stream(stream, device):
+    if stream is None:
+        import torch
+        stream = torch.cuda.current_stream(device)
+    return ctypes.c_void_p(getattr(stream, "cuda_stream", stream))
+
+
+class Sorter:
+    """One radx_hip_sorter handle.  key_bytes 4|8, value_bytes 0|4."""
+
+    def __init__(self, max_n, key_bytes=4, value_bytes=0, device=0):
+        self.max_n = int(max_n)
+        self.key_bytes = key_bytes
+        self.value_bytes = value_bytes
+        self.device = device
+        self._h = ctypes.c_void_p(None)
+        capi.check(capi.lib.radx_hip_create(device, self.max_n, key_bytes, value_bytes,
+                                            ctypes.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            capi.check(capi.lib.radx_hip_destroy(self._h))
+            self._h = ctypes.c_void_p(None)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, t, elem, n, name):
+        if t is None:
+            return
+        if not t.is_cuda or not t.is_contiguous():
+            raise ValueError("%s must be a contiguous device tensor" % name)
+        if t.element_size() != elem:
+            raise ValueError("%s has %d-byte elements, sorter expects %d" % (name, t.element_size(), elem))
+        if t.numel() < n:
+            raise ValueError("%s holds %d elements, need %d" % (name, t.numel(), n))
+
+    def _args(self, keys, swap, vals, vals_swap, n):
+        n = keys.numel() if n is None else int(n)
+        self._check(keys, self.key_bytes, n, "keys")
+        self._check(swap, self.key_bytes, n, "swap")
+        self._check(vals, 4, n, "vals")
+        self._check(vals_swap, 4, n, "vals_swap")
+        return n
+
+    def sort(self, keys, swap, vals=None, vals_swap=None, n=None, stream=None):
+        n = self._args(keys, swap, vals, vals_swap, n)
+        capi.check(capi.lib.radx_hip_sort(self._h, _ptr(keys), _ptr(swap), _ptr(vals), _ptr(vals_swap),
+                                          n, _stream(stream, self.device)))
+
+    def sort_bits(self, keys, swap, begin_bit, end_bit, vals=None, vals_swap=None, n=None, stream=None):
+        n = self._args(keys, swap, vals, vals_swap, n)
+        capi.check(capi.lib.radx_hip_sort_bits(self._h, _ptr(keys), _ptr(swap), _ptr(vals),
+                                               _ptr(vals_swap), n, begin_bit, end_bit,
+                                               _stream(stream, self.device)))
+
+    def run_pass(self, keys_in, keys_out, bit, num_bits=4, vals_in=None, vals_out=None, n=None, stream=None):
+        n = self._args(keys_in, keys_out, vals_in, vals_out, n)
+        capi.check(capi.lib.radx_hip_pass(self._h, _ptr(keys_in), _ptr(keys_out), _ptr(vals_in),
+                                          _ptr(vals_out), n, bit, num_bits, _stream(stream, self.device)))
+
+    def geometry(self, n):
+        tile, tiles = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        capi.check(capi.lib.radx_hip_geometry(self._h, int(n), ctypes.byref(tile), ctypes.byref(tiles)))
+        return tile.value, tiles.value
+
+    def tables(self, n, stream=None):
+        """(counts, offsets) of the last pass as uint32 arrays of shape [16, num_tiles]."""
+        _, tiles = self.geometry(n)
+        counts = np.empty((16, tiles), dtype=np.uint32)
+        offsets = np.empty((16, tiles), dtype=np.uint32)
+        capi.check(capi.lib.radx_hip_copy_tables(self._h, int(n), counts.ctypes.data_as(ctypes.c_void_p),
+                                                 offsets.ctypes.data_as(ctypes.c_void_p),
+                                                 _stream(stream, self.device)))
+        return counts, offsets
+
+    def digit_starts(self, stream=None):
+        out = (ctypes.c_uint32 * 17)()
+        capi.check(capi.lib.radx_hip_digit_starts(self._h, out, _stream(stream, self.device)))
+        return np.array(out, dtype=np.uint32)
+
+    def profile(self, enable=True):
+        capi.check(capi.lib.radx_hip_profile(self._h, 1 if enable else 0))
+
+    def kernel_times(self):
+        """{'hist'|'scan'|'scatter': (total_ms, launches)} since the last call; synchronises."""
+        ms = (ctypes.c_double * 3)()
+        cnt = (ctypes.c_uint64 * 3)()
+        capi.check(capi.lib.radx_hip_kernel_times(self._h, ms, cnt))
+        return {k: (ms[i], int(cnt[i])) for i, k in enumerate(("hist", "scan", "scatter"))}
+
+
+def generate_u32(keys, seed, n=None, stream=None):
+    n = keys.numel() if n is None else int(n)
+    capi.check(capi.lib.radx_hip_generate_u32(_ptr(keys), n, seed & 0xFFFFFFFF,
+                                              _stream(stream, keys.device)))
+
+
+def generate_u64(keys, vals, seed, n=None, stream=None):
+    n = keys.numel() if n is None else int(n)
+    capi.check(capi.lib.radx_hip_generate_u64(_ptr(keys), _ptr(vals), n, seed & 0xFFFFFFFF,
+                                              _stream(stream, keys.device)))
+
+
+def check_sorted(keys, vals=None, n=None, stream=None):
+    """Number of adjacent order (and, with vals, stability) violations; synchronises."""
+    n = keys.numel() if n is None else int(n)
+    bad = ctypes.c_uint64(0)
+    capi.check(capi.lib.radx_hip_check_sorted(_ptr(keys), _ptr(vals), n, keys.element_size(),
+                                              ctypes.byref(bad), _stream(stream, keys.device)))
+    return bad.value
+
+
+def checksum(keys, n=None, stream=None):
+    """(sum, xor, mixed sum) of the keys, each mod 2^64; synchronises."""
+    n = keys.numel() if n is None else int(n)
+    out = (ctypes.c_uint64 * 3)()
+    capi.check(capi.lib.radx_hip_checksum(_ptr(keys), n, keys.element_size(), out,
+                                          _stream(stream, keys.device)))
+    return tuple(int(v) for v in out)
