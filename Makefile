@@ -24,11 +24,11 @@ $(ORACLE): oracle/radx_oracle.c oracle/radx_oracle.h
 $(CPUSORT): oracle/cpu_sort.cpp
 	$(CXX) -O3 -std=c++17 -fPIC -shared -fopenmp -Wall -o $@ oracle/cpu_sort.cpp
 
-$(HARNESS): harness/sort_test.cpp $(LIB) $(CPUSORT) $(wildcard include/radx/*.hpp) include/radx_hip.h
+$(HARNESS): harness/sort_test.cpp $(LIB) $(wildcard include/radx/*.hpp) include/radx_hip.h
 	$(CXX) -O2 -std=c++17 -fopenmp -Wall -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
 	    -o $@ harness/sort_test.cpp \
-	    -Lradx_amd/lib -lradx_hip -Loracle -lradx_cpusort -L/opt/rocm/lib -lamdhip64 \
-	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,'$$ORIGIN/../oracle' -Wl,-rpath,/opt/rocm/lib
+	    -Lradx_amd/lib -lradx_hip -L/opt/rocm/lib -lamdhip64 \
+	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,/opt/rocm/lib
 
 resources:
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null radx_amd/csrc/radx_hip.hip 2>&1 | \

@@ -1,0 +1,245 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Gkeys/s of the uint32 LSD radix sort on 1/2/4/8 MI355X.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n L]
+
+One step = one complete sort (all 8 four-bit passes) of one batch of 2^L uniform uint32 keys
+per GPU that is already resident in HBM.  N > 1 is launched by torch.distributed.run, one rank
+per GPU; a step is then MSD split + one all-to-all-v over RCCL + the local passes, and the
+per-GPU batch stays 2^L (weak scaling).  Every step sorts a DIFFERENT pre-generated batch, so
+no step ever sees already-sorted input.  Rank 0 prints one JSON line.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM_GBPS = 8000.0  # MI355X HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log2n", type=int, default=30, help="log2 of keys per GPU (30 = README headline size)")
+    ap.add_argument("--cpu-log2n", type=int, default=27, help="log2 of the CPU-baseline sample")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(log2n):
+    """Parallel std::sort of a bounded sample on the host cores (oracle/cpu_sort.cpp), next to the
+    reference's own comparator call std::stable_sort(std::execution::par, ...) (src/test/sort.cpp:218-219)."""
+    import numpy as np
+    import oracle
+    n = 1 << log2n
+    keys = oracle.generate_u32(n, 12345)
+    best = None
+    for _ in range(2):
+        k = keys.copy()
+        t0 = time.perf_counter()
+        oracle.cpu.radx_cpu_parallel_sort_u32(k.ctypes.data_as(ctypes.c_void_p), n)
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    assert np.all(k[1:] >= k[:-1])
+    m = 1 << min(log2n, 25)
+    k = keys[:m].copy()
+    t0 = time.perf_counter()
+    oracle.cpu.radx_cpu_stable_sort_u32(k.ctypes.data_as(ctypes.c_void_p), m)
+    stable_dt = time.perf_counter() - t0
+    return {
+        "value": round(n / best / 1e9, 4), "unit": "Gkeys/s", "cores": int(oracle.cpu.radx_cpu_threads()),
+        "kind": "port",
+        "sample": "2^%d hashed uint32 keys, __gnu_parallel::sort (OpenMP), best of 2: %.3f s" % (log2n, best),
+        "reference_call": {
+            "what": "std::stable_sort(std::execution::par) on 2^%d keys, PSTL backend '%s'"
+                    % (min(log2n, 25), oracle.cpu.radx_cpu_pstl_backend().decode()),
+            "value": round(m / stable_dt / 1e9, 4), "unit": "Gkeys/s"},
+    }
+
+
+def pmc_traffic():
+    """HBM bytes per scatter launch from the committed rocprofv3 PMC passes, if present."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    import radx_amd
+    from radx_amd.sharded import HipEngine, ShardedSorter
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with `python -m torch.distributed.run "
+                     "--nproc-per-node %d ...`" % (args.gpus, args.gpus))
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = 1 << args.log2n
+    K, W = args.steps, args.warmup
+    cap = n if world == 1 else ShardedSorter.suggest_capacity(n)
+    batch_bytes = cap * 4
+    free_b, _ = torch.cuda.mem_get_info(dev)
+    budget = int(free_b * 0.75) - 2 * batch_bytes
+    pool_n = max(1, min(K + W, budget // batch_bytes))
+    wall_mode = pool_n >= K + W
+
+    pool = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(pool_n)]
+    work = torch.empty(cap, dtype=torch.int32, device=dev)
+
+    def fill(i, step):
+        radx_amd.generate_u32(pool[i], seed=(step + 1) * 7919 + rank * 104729, n=n)
+
+    for i in range(pool_n):
+        fill(i, i)
+    engine = HipEngine(cap, 4, local_rank)
+    sharder = ShardedSorter(engine) if world > 1 else None
+    checks = radx_amd.checksum(pool[(K + W - 1) % pool_n], n=n) if world == 1 else None
+
+    def step(i):
+        if world == 1:
+            engine.sorter.sort(pool[i], work, n=n)
+            return n
+        return sharder.sort(pool[i], work, n)[1]
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for w in range(W):
+        step(w % pool_n)
+    fence()
+    engine.sorter.profile(True)
+    last_len = n
+    if wall_mode:
+        t0 = time.perf_counter()
+        for s in range(K):
+            last_len = step(W + s)
+        fence()
+        elapsed = time.perf_counter() - t0
+        timing = "wall clock over K steps, each on its own pre-generated batch"
+    else:
+        # The batches do not all fit in HBM: regenerate between steps and time each step with events.
+        elapsed = 0.0
+        for s in range(K):
+            i = (W + s) % pool_n
+            fill(i, W + s)
+            fence()
+            if s == K - 1 and world == 1:
+                checks = radx_amd.checksum(pool[i], n=n)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            last_len = step(i)
+            e1.record()
+            fence()
+            elapsed += e0.elapsed_time(e1) / 1e3
+        timing = "per-step HIP events (batch pool of %d regenerated between steps)" % pool_n
+    kt = engine.sorter.kernel_times()
+    engine.sorter.profile(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # correctness of the last timed step, outside the timed region
+    last = pool[(W + K - 1) % pool_n]
+    violations = radx_amd.check_sorted(last, n=last_len)
+    verified = violations == 0
+    if world == 1:
+        verified = verified and radx_amd.checksum(last, n=n) == checks
+    else:
+        b = world.bit_length() - 1
+        top = (last[:last_len] >> (32 - b)) & ((1 << b) - 1) if b else None
+        if top is not None:
+            verified = verified and bool((top == rank).all().item())
+        tot = torch.tensor([last_len], dtype=torch.int64, device=dev)
+        dist.all_reduce(tot)
+        verified = verified and int(tot.item()) == n * world
+        v = torch.tensor([1 if verified else 0], device=dev)
+        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        verified = bool(v.item())
+
+    # device-to-device copy ceiling of this GPU, same run
+    src, dst = pool[0], work
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    dst.copy_(src)
+    e0.record()
+    for _ in range(3):
+        dst.copy_(src)
+    e1.record()
+    torch.cuda.synchronize()
+    copy_gbps = 3 * 2 * batch_bytes / (e0.elapsed_time(e1) / 1e3) / 1e9
+
+    if rank == 0:
+        ms_per_step = elapsed / K * 1e3
+        value = world * n * K / elapsed / 1e9
+        scatter_ms, scatter_launches = kt["scatter"]
+        # algorithmic bytes of one scatter launch: every key read once and written once
+        # (on N > 1 the shard length varies by a fraction of a percent around n)
+        alg_bytes = 2.0 * 4 * n
+        avg_ms = scatter_ms / max(1, scatter_launches)
+        achieved = alg_bytes / (avg_ms / 1e3) / 1e9 if avg_ms > 0 else 0.0
+        traffic = pmc_traffic()
+        out = {
+            "metric": "Gkeys/s (uint32) at 1/2/4/8 MI355X; achieved HBM GB/s vs peak",
+            "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {
+                "workload": "2^%d uniform (hashed) uint32 keys per GPU, full sort = 8 x 4-bit LSD passes%s"
+                            % (args.log2n, "" if world == 1 else
+                               ", MSD split on the top %d bits + one RCCL all-to-all-v + local passes"
+                               % (world.bit_length() - 1)),
+                "keys_per_gpu": n, "total_keys": n * world, "key_bytes": 4, "passes": 8,
+                "parallelism": "1 GPU" if world == 1 else "msd-shard x%d" % world},
+            "verified": verified, "timing": timing,
+            "sort_roofline": {
+                "algorithmic_bytes_per_key": 64, "achieved_GBps": round(64.0 * value, 1),
+                "frac_of_8TBps": round(64.0 * value / world / PEAK_HBM_GBPS, 4),
+                "copy_ceiling_GBps": round(copy_gbps, 1)},
+            "kernels_ms_per_launch": {k: round(v[0] / max(1, v[1]), 4) for k, v in kt.items()},
+            "roofline": {
+                "kernel": "scatter_kernel<uint32>", "bound": "hbm", "achieved": round(achieved, 1),
+                "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
+                "traffic": traffic.get("scatter_bytes_per_launch") if traffic else None,
+                "launches": scatter_launches, "avg_launch_ms": round(avg_ms, 4),
+                "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if world == 1 and not args.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_log2n)
+        elif world == 1:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+
+    engine.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,184 @@
+#pragma once
+// radx_internal.hpp — InternalInterface, InputInterface, Algorithm, Sort<T>, Radix with the
+// reference's method names and call order (reference: include/radx/radx_internal.hpp:8-148,
+// include/radx/radx_implement.inl:315-490), bound to the gfx950 engine through include/radx_hip.h.
+//
+//   auto helper  = std::make_shared<radx::PhysicalDeviceHelper>(radx::PhysicalDevice(0));
+//   auto device  = std::make_shared<radx::Device>()->initialize(radx::LogicalDevice(0), helper);
+//   auto program = std::make_shared<radx::Radix>(); program->initialize(device);
+//   auto sorter  = std::make_shared<radx::Sort<radx::Radix>>(); sorter->initialize(device, program, n);
+//   auto input   = std::make_shared<radx::InputInterface>(device);
+//   input->setElementCount(n).setKeysBufferInfo(keys).setSwapBufferInfo(swap).buildDescriptorSet();
+//   sorter->command(radx::CommandBuffer(stream), input);   // enqueues; result lands in `keys`
+#include "radx_buffer.hpp"
+#include "radx_device.hpp"
+
+namespace radx {
+
+    // Scratch owned by one Sort object: the engine handle with its histogram / prefix-scan tables
+    // (reference: InternalInterface::bufferMemory, radx_internal.hpp:11, sized by
+    // Radix::createInternalMemory, radx_implement.inl:450-490).
+    class InternalInterface {
+    protected:
+        std::shared_ptr<Device> device{};
+        radx_hip_sorter* sorter = nullptr;
+        std::size_t maxElementCount = 1024 * 1024;
+        int keyBytes = 4, valueBytes = 0;
+
+    public:
+        friend class Algorithm;
+        friend class Radix;
+        InternalInterface() {}
+        InternalInterface(const std::shared_ptr<Device>& device) : device(device) {}
+        InternalInterface(const InternalInterface&) = delete;
+        InternalInterface& operator=(const InternalInterface&) = delete;
+        ~InternalInterface() { if (sorter) (void)radx_hip_destroy(sorter); }
+
+        InternalInterface& setMaxElementCount(const std::size_t& elementCount = 0) { maxElementCount = elementCount; return *this; }
+        // reference: buildMemory(memorySize) allocates the one scratch buffer (radx_internal.hpp:40)
+        InternalInterface& buildMemory(int keyBytes, int valueBytes) {
+            if (sorter) { check_abi(radx_hip_destroy(sorter)); sorter = nullptr; }
+            this->keyBytes = keyBytes; this->valueBytes = valueBytes;
+            check_abi(radx_hip_create(device->ordinal(), maxElementCount, keyBytes, valueBytes, &sorter));
+            return *this;
+        }
+        // No descriptor sets in HIP; kept so reference call sequences compile.
+        InternalInterface& buildDescriptorSet() { return *this; }
+
+        std::size_t getMaxElementCount() const { return maxElementCount; }
+        std::size_t getMemorySize() const { return radx_hip_scratch_bytes(maxElementCount, keyBytes); }
+        radx_hip_sorter* handle() const { return sorter; }
+        int getKeyBytes() const { return keyBytes; }
+        int getValueBytes() const { return valueBytes; }
+    };
+
+    // Non-owning views of the caller's buffers (reference: radx_internal.hpp:49-73).
+    class InputInterface {
+    protected:
+        std::shared_ptr<Device> device{};
+        bool built = false;
+
+    public:
+        friend class Algorithm;
+        InputInterface() {}
+        InputInterface(const std::shared_ptr<Device>& device) : device(device) {}
+
+        DescriptorBufferInfo keysBufferInfo{}, swapBufferInfo{};
+        // Payload that travels with its key: the binding the reference declares and never wires
+        // (shaders-sdk/radix/includes.glsl:151; radx_implement.inl:283,301).
+        DescriptorBufferInfo valuesBufferInfo{}, valuesSwapBufferInfo{};
+        std::size_t elementCount = 0;
+
+        InputInterface& setKeysBufferInfo(const DescriptorBufferInfo& keys = {}) { keysBufferInfo = keys; built = false; return *this; }
+        InputInterface& setSwapBufferInfo(const DescriptorBufferInfo& swap = {}) { swapBufferInfo = swap; built = false; return *this; }
+        InputInterface& setValuesBufferInfo(const DescriptorBufferInfo& vals = {}) { valuesBufferInfo = vals; built = false; return *this; }
+        InputInterface& setValuesSwapBufferInfo(const DescriptorBufferInfo& swap = {}) { valuesSwapBufferInfo = swap; built = false; return *this; }
+        InputInterface& setElementCount(const std::size_t& elementCount = 0) { this->elementCount = elementCount; built = false; return *this; }
+
+        // reference: radx_implement.inl:357-388 creates buffer views and writes the descriptor set;
+        // here it validates what the kernels assume about the views.
+        InputInterface& buildDescriptorSet() {
+            auto aligned = [](const DescriptorBufferInfo& b) { return (reinterpret_cast<std::uintptr_t>(b.address()) & 15u) == 0; };
+            if (elementCount > 0) {
+                if (!keysBufferInfo.buffer || !swapBufferInfo.buffer)
+                    throw Error(static_cast<int>(hipErrorInvalidValue), "InputInterface: keys/swap buffer not set");
+                if (!aligned(keysBufferInfo) || !aligned(swapBufferInfo))
+                    throw Error(static_cast<int>(hipErrorInvalidValue), "InputInterface: keys/swap must be 16-byte aligned");
+                if ((valuesBufferInfo.buffer != nullptr) != (valuesSwapBufferInfo.buffer != nullptr))
+                    throw Error(static_cast<int>(hipErrorInvalidValue), "InputInterface: values and values-swap go together");
+                if (valuesBufferInfo.buffer && (!aligned(valuesBufferInfo) || !aligned(valuesSwapBufferInfo)))
+                    throw Error(static_cast<int>(hipErrorInvalidValue), "InputInterface: value buffers must be 16-byte aligned");
+            }
+            built = true;
+            return *this;
+        }
+        bool isBuilt() const { return built; }
+    };
+
+    // reference: radx_internal.hpp:77-101
+    class Algorithm : public std::enable_shared_from_this<Algorithm> {
+    protected:
+        std::shared_ptr<Device> device{};
+        virtual Result command(const CommandBuffer&, const std::unique_ptr<InternalInterface>&,
+                               const std::shared_ptr<InputInterface>&, Result& res) { return res = SUCCESS; }
+        virtual Result createInternalMemory(std::unique_ptr<InternalInterface>&, const std::size_t& = 1024 * 1024) { return SUCCESS; }
+
+    public:
+        Algorithm() {}
+        virtual ~Algorithm() {}
+        template <class T> friend class Sort;
+        virtual Result initialize(const std::shared_ptr<Device>& device) { this->device = device; return SUCCESS; }
+    };
+
+    // reference: radx_internal.hpp:104-134
+    template <class T>
+    class Sort : public std::enable_shared_from_this<Sort<T>> {
+    protected:
+        std::shared_ptr<T> algorithm{};
+        std::shared_ptr<Device> device{};
+        std::unique_ptr<InternalInterface> internalInterface{};
+
+    public:
+        virtual ~Sort() {}
+
+        virtual Sort<T>& initialize(const std::shared_ptr<Device>& device, const std::shared_ptr<T>& algorithm,
+                                    const std::size_t& maxElementCount = 1024 * 1024) {
+            this->device = device; this->algorithm = algorithm;
+            this->internalInterface = std::make_unique<InternalInterface>(this->device);
+            this->algorithm->createInternalMemory(this->internalInterface, maxElementCount);
+            return *this;
+        }
+
+        // Enqueue the sort on cmdBuf's stream.  One sort in flight per Sort object.
+        virtual Sort<T>& command(const CommandBuffer& cmdBuf, std::shared_ptr<InputInterface>& inputInterface) {
+            Result res = SUCCESS;
+            algorithm->command(cmdBuf, internalInterface, inputInterface, res);
+            return *this;
+        }
+
+        const InternalInterface& getInternalInterface() const { return *internalInterface; }
+    };
+
+    // reference: radx_internal.hpp:137-148, radx_implement.inl:391-490
+    class Radix : public Algorithm {
+    protected:
+        int keyBytes = 4, valueBytes = 0;
+
+        // reference: radx_implement.inl:421-447 — the pass loop, one C-ABI call here
+        Result command(const CommandBuffer& cmdBuf, const std::unique_ptr<InternalInterface>& internalInterface,
+                       const std::shared_ptr<InputInterface>& inputInterface, Result& res) override {
+            if (!inputInterface->isBuilt()) inputInterface->buildDescriptorSet();
+            const std::size_t n = inputInterface->elementCount;
+            const std::size_t need = n * static_cast<std::size_t>(keyBytes);
+            if (n && (inputInterface->keysBufferInfo.range < need || inputInterface->swapBufferInfo.range < need))
+                throw Error(static_cast<int>(hipErrorInvalidValue), "Radix::command: keys/swap range smaller than elementCount");
+            res = radx_hip_sort(internalInterface->handle(), inputInterface->keysBufferInfo.address(),
+                                inputInterface->swapBufferInfo.address(), inputInterface->valuesBufferInfo.address(),
+                                inputInterface->valuesSwapBufferInfo.address(), n, cmdBuf.stream);
+            check_abi(res);
+            return res;
+        }
+
+        // reference: radx_implement.inl:450-490
+        Result createInternalMemory(std::unique_ptr<InternalInterface>& internalInterface,
+                                    const std::size_t& maxElementCount = 1024 * 1024) override {
+            internalInterface->setMaxElementCount(maxElementCount);
+            internalInterface->buildMemory(keyBytes, valueBytes).buildDescriptorSet();
+            return SUCCESS;
+        }
+
+    public:
+        Radix() {}
+        template <class T> friend class Sort;
+
+        // Key width (4 or 8 bytes) and payload width (0 or 4).  The reference fixes these at shader
+        // compile time (KEYTYPE, shaders-sdk/radix/includes.glsl:128-135); set them before
+        // Sort::initialize.
+        Radix& setKeyBytes(int bytes) { keyBytes = bytes; return *this; }
+        Radix& setValueBytes(int bytes) { valueBytes = bytes; return *this; }
+
+        // reference: radx_implement.inl:391-418 builds five pipelines; the kernels here are
+        // already part of the loaded code object.
+        Result initialize(const std::shared_ptr<Device>& device) override { this->device = device; return SUCCESS; }
+    };
+}

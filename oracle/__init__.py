@@ -8,9 +8,9 @@ import os
 
 import numpy as np
 
-_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-ORACLE_PATH = os.path.join(_ROOT, "oracle", "libradx_oracle.so")
-CPUSORT_PATH = os.path.join(_ROOT, "oracle", "libradx_cpusort.so")
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_PATH = os.path.join(_HERE, "libradx_oracle.so")
+CPUSORT_PATH = os.path.join(_HERE, "libradx_cpusort.so")
 
 
 class Config(ctypes.Structure):
