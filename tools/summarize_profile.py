@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Digest gpurun_out/prof_<tag>/ (written by tools/profile.sh) into profiles/:
+  profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary, verbatim
+  profiles/<tag>_pmc.csv            per-kernel averages of FETCH_SIZE / WRITE_SIZE (separate passes)
+  profiles/pmc_traffic.json         HBM bytes per launch of the dominant kernel, corrected for gfx950
+gfx950 correction: FETCH_SIZE counts 64 B per 128-B request, so coalesced reads are doubled;
+WRITE_SIZE is exact (calibrated in the same run on generate_u32_kernel, which writes exactly 4 B/key
+with the scatter's store width, and on hist_kernel / checksum_kernel, which read exactly 4 B/key)."""
+import collections
+import csv
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src = os.path.join(root, "gpurun_out", "prof_" + tag)
+dst = os.path.join(root, "profiles")
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
+shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
+
+rows = []
+per = {}
+for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
+    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(f)):
+        agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+    for name, v in agg.items():
+        avg_kb = sum(v) / len(v)
+        rows.append((name, counter, len(v), avg_kb))
+        per.setdefault(name, {})[counter] = avg_kb
+with open(os.path.join(dst, tag + "_pmc.csv"), "w", newline="") as f:
+    w = csv.writer(f)
+    w.writerow(["Kernel_Name", "Counter", "Dispatches", "Average_KB_raw", "Average_bytes_corrected"])
+    for name, counter, cnt, kb in sorted(rows):
+        w.writerow([name, counter, cnt, "%.1f" % kb, "%.0f" % (kb * 1024 * (2 if counter == "FETCH_SIZE" else 1))])
+
+
+def corrected(prefix):
+    for name, c in per.items():
+        if prefix in name:
+            return 2 * c.get("FETCH_SIZE", 0) * 1024, c.get("WRITE_SIZE", 0) * 1024
+    return None, None
+
+
+out = {"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+       "`python3 bench.py --steps 1 --warmup 0 --no-cpu`, 2^30 uint32 keys",
+       "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); WRITE_SIZE exact"}
+for key, prefix in (("scatter", "scatter_kernel"), ("hist", "hist_kernel")):
+    rd, wr = corrected(prefix)
+    if rd is not None:
+        out[key + "_read_bytes_per_launch"] = rd
+        out[key + "_write_bytes_per_launch"] = wr
+        out[key + "_bytes_per_launch"] = rd + wr
+json.dump(out, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1))
