@@ -18,7 +18,7 @@
  *       reached through radx::Sort<T>::command include/radx/radx_internal.hpp:129-132.
  *       Work is enqueued on the caller's stream exactly as the reference records into the
  *       caller's command buffer; nothing has executed when the call returns.
- *   radx_hip_pass / radx_hip_copy_tables
+ *   radx_hip_pass / radx_hip_pass_fused / radx_hip_copy_tables
  *       one iteration of the loop at radx_implement.inl:427-444 (counting, partition,
  *       scattering: shaders-sdk/radix/{counting,partition,scattering}.comp) with the
  *       histogram (binding 3) and prefix-sum (binding 4) tables readable afterwards.
@@ -86,24 +86,44 @@ int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* va
 
 /*
  * Enqueue ONE pass (histogram -> scan -> scatter) reading keys_in / vals_in and writing
- * keys_out / vals_out, on the digit of `num_bits` (1..4) bits starting at bit `bit`.
+ * keys_out / vals_out, on the digit of `num_bits` (0..4) bits starting at bit `bit`.
  * The tables stay in the sorter's scratch until the next call.
  */
 int radx_hip_pass(radx_hip_sorter* s, const void* keys_in, void* keys_out, const void* vals_in,
                   void* vals_out, uint64_t n, int bit, int num_bits, void* stream);
 
 /*
- * Tile geometry of the engine for n elements: keys per tile and number of tiles.
- * Tile t covers elements [t*tile, min((t+1)*tile, n)).
+ * One pass as radx_hip_sort chains them.  While scattering, the pass also accumulates the
+ * histogram table of the NEXT pass (digit next_num_bits bits wide at next_bit; next_bit < 0
+ * disables this), which is the table counting would produce on this pass's output.  With
+ * use_fused_counts != 0 the pass takes its own histogram from what the previous
+ * radx_hip_pass_fused call accumulated (same n, same digit) instead of running the histogram
+ * kernel.  radx_hip_copy_tables shows the tables either way.
  */
-int radx_hip_geometry(const radx_hip_sorter* s, uint64_t n, uint32_t* tile_keys,
-                      uint32_t* num_tiles);
+int radx_hip_pass_fused(radx_hip_sorter* s, const void* keys_in, void* keys_out, const void* vals_in,
+                        void* vals_out, uint64_t n, int bit, int num_bits, int next_bit,
+                        int next_num_bits, int use_fused_counts, void* stream);
 
 /*
- * Synchronise `stream` and copy the tables of the last pass to host memory, both laid
- * out [RADX_HIP_RADICES][num_tiles] (digit-major):
- *   counts[d][t]  = keys of tile t whose digit is d          (reference counts[g][r])
- *   offsets[d][t] = first output index for digit d of tile t (reference partitions[g][r])
+ * Tuning knob.  fuse_histogram (default 1): let every scatter pass of radx_hip_sort produce the
+ * next pass's histogram; 0 runs the histogram kernel every pass.  The sorted result and the
+ * tables do not depend on it.
+ */
+int radx_hip_tune(radx_hip_sorter* s, int fuse_histogram);
+
+/*
+ * Geometry of the engine for n elements, i.e. get_blocks_info
+ * (shaders-sdk/radix/includes.glsl:162-173) for a grid of ceil(n / tile) workgroups: keys per
+ * tile (16 KiB of keys) and number of tiles.  Workgroup g owns elements
+ * [g*tile, min((g+1)*tile, n)).
+ */
+int radx_hip_geometry(const radx_hip_sorter* s, uint64_t n, uint32_t* tile_keys, uint32_t* num_tiles);
+
+/*
+ * Synchronise `stream` and copy the tables of the last pass to host memory, both laid out
+ * [num_tiles][RADX_HIP_RADICES] like the reference's bindings 3 and 4:
+ *   counts[g][r]  = keys of tile g whose digit is r           (counting.comp:45)
+ *   offsets[g][r] = first output index for digit r of tile g (partition.comp:26)
  * Either pointer may be NULL.
  */
 int radx_hip_copy_tables(radx_hip_sorter* s, uint64_t n, uint32_t* counts, uint32_t* offsets,

@@ -74,7 +74,7 @@ def head_config():
 
 
 def engine_config(n, key_bytes=4, bits=4):
-    """The HIP engine's decomposition: one workgroup per 16 KiB tile."""
+    """The HIP engine's decomposition: get_blocks_info with one workgroup per 16 KiB tile."""
     tile = 4096 if key_bytes == 4 else 2048
     return Config(bits=bits, grid=max(1, -(-n // tile)), wave=64, vec=tile // 64)
 

@@ -2,28 +2,38 @@
 //
 // One pass = histogram -> scan -> scatter on a 4-bit digit, the three phases the reference
 // dispatches per pass (include/radx/radx_implement.inl:427-444; shaders-sdk/radix/counting.comp,
-// partition.comp, scattering.comp).  The decomposition is this engine's own:
+// partition.comp, scattering.comp).  How the work is cut is this engine's own:
 //
-//   * the input is cut into tiles of 16 KiB of keys (4096 uint32 / 2048 uint64), one 256-thread
-//     workgroup per tile, instead of the reference's fixed 108 workgroups looping over 256-key
-//     tiles (include/radx/radx_internal.hpp:143, shaders-sdk/radix/includes.glsl:162-173);
-//   * the tables are digit-major, counts[d][tile], so the reference's two-phase partition
-//     (partition.comp:33-48 per radix over workgroups, :51-67 over radices) is ONE linear
-//     exclusive scan of 16*num_tiles words;
-//   * inside a tile every key gets its stable rank from per-thread digit counters in LDS
-//     (packed 2 x 16 bit, laid out [digit & 7][thread]) and one block-wide scan over them, the
-//     tile is written to LDS in sorted order, and each digit's run leaves the CU as contiguous
+//   * Chunking is the reference's get_blocks_info (shaders-sdk/radix/includes.glsl:162-173) with a
+//     grid that grows with n instead of the fixed 108 workgroups (include/radx/radx_internal.hpp:143):
+//     one workgroup per tile of 16 KiB of keys (4096 uint32 / 2048 uint64), so every workgroup's
+//     chunk is exactly one tile.
+//   * The tables keep the reference's layout, counts[workgroup][radix] and
+//     partitions[workgroup][radix] (counting.comp:45, partition.comp:25-26): one 64-byte line per
+//     workgroup.
+//   * Inside a tile every key gets its stable rank from per-thread digit counters in LDS
+//     (packed 2 x 16 bit, laid out [digit & 7][thread]) and one block-wide scan over them; the
+//     tile is written to LDS in sorted order and each digit's run leaves the CU as contiguous
 //     dword stores.  Address order is preserved per digit, which is the reference's rank
 //     (scattering.comp:119-123,141-143).
+//   * Only the first pass of a sort runs the histogram kernel.  While scatter pass p stores its
+//     keys it also counts, per destination tile, the NEXT digit of every key it stores, and adds
+//     those counts to the table pass p+1 will scan: the table pass p+1 needs is exactly "digit
+//     counts per tile of pass p's output", and pass p is the one kernel that knows where every key
+//     lands.  A digit run of one source tile is contiguous and no longer than a tile, so it
+//     touches at most 2 destination tiles: at most 2*16*16 counters per workgroup, kept in LDS
+//     and flushed once with global atomic adds.
 //
-// All cross-wave LDS hand-offs are separated by __syncthreads().
+// All cross-wave LDS hand-offs are separated by __syncthreads().  Workgroups never wait on each
+// other inside a launch; the only inter-workgroup traffic is no-return atomic adds whose sums are
+// read by a later kernel on the same stream.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
-#include <mutex>
 #include <new>
 #include <vector>
 
@@ -31,18 +41,17 @@
 
 namespace {
 
-constexpr int kBlock = 256;           // threads per workgroup (4 waves of 64)
+constexpr int kBlock = 256;             // threads per workgroup (4 waves of 64)
 constexpr int kRadices = RADX_HIP_RADICES;
 constexpr int kDigitBits = RADX_HIP_BITS_PER_PASS;
-constexpr int kThreadDwords = 16;     // every thread owns 64 B of keys
+constexpr int kThreadDwords = 16;       // every thread owns 64 B of keys
 constexpr int kTileDwords = kBlock * kThreadDwords;  // 16 KiB of keys per tile
-constexpr int kRowStride = 20;        // LDS dwords per thread row: 16 + 4 pad (bank spread for b128 reads)
 constexpr int kCtrRows = kRadices / 2;  // packed counters: digit d lives in row d&7, half d>>3
-constexpr int kScanChunk = 2048;      // table words scanned by one workgroup (256 threads x 8)
+constexpr int kScanBlocks = 256;        // table rows (workgroups) scanned by one scan workgroup
 
 template <typename K> struct KeyTraits;
-template <> struct KeyTraits<uint32_t> { static constexpr int kpt = 16; };
-template <> struct KeyTraits<uint64_t> { static constexpr int kpt = 8; };
+template <> struct KeyTraits<uint32_t> { static constexpr int kpt = 16; static constexpr int log_tile = 12; };
+template <> struct KeyTraits<uint64_t> { static constexpr int kpt = 8;  static constexpr int log_tile = 11; };
 
 // ---------------------------------------------------------------------------------------------
 // device helpers
@@ -52,7 +61,7 @@ template <> struct KeyTraits<uint64_t> { static constexpr int kpt = 8; };
 // bijection gives each of those 8 groups one contiguous range of tiles: tiles that run next to
 // each other in time on one XCD are neighbours in memory, and the two halves of an output line
 // that straddles two tiles' runs meet in the same L2.  Speed only; any placement is correct.
-__device__ __forceinline__ uint32_t tile_of_block(uint32_t bid, uint32_t nwg) {
+__device__ __forceinline__ uint32_t tile_of_workgroup(uint32_t bid, uint32_t nwg) {
     const uint32_t q = nwg >> 3, r = nwg & 7u, x = bid & 7u, k = bid >> 3;
     return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + k;
 }
@@ -83,21 +92,32 @@ template <> __device__ __forceinline__ void unpack4<uint64_t>(const uint4& v, ui
     out[1] = (static_cast<uint64_t>(v.w) << 32) | v.z;
 }
 
-// Inclusive scan over the 64 lanes of a wave.
-__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t up = __shfl_up(v, off, 64);
-        if (lane >= static_cast<uint32_t>(off)) v += up;
-    }
+// Inclusive scan over the 64 lanes of a wave with DPP adds: shifts by 1, 2, 4, 8 inside each row
+// of 16 lanes, then the row totals are broadcast into the following rows (row_bcast:15 into rows
+// 1 and 3, row_bcast:31 into rows 2 and 3).  Lanes a step does not reach add 0.
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x111, 0xf, 0xf, false));  // row_shr:1
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x112, 0xf, 0xf, false));  // row_shr:2
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x114, 0xf, 0xf, false));  // row_shr:4
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x118, 0xf, 0xf, false));  // row_shr:8
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x142, 0xa, 0xf, false));  // row_bcast:15
+    v += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(v), 0x143, 0xc, 0xf, false));  // row_bcast:31
     return v;
 }
 
+// The tile image in LDS used to hand every thread its own 64 consecutive bytes: logical dword
+// (row, c), row = owning thread, c = 0..15, lives at row*16 + ((c/4) ^ ((row >> 2) & 3))*4 + c%4.
+// The XOR on the 16-byte chunk index makes both the coalesced ds_write_b128 (lanes 4r..4r+3 fill
+// row r) and the per-thread ds_read_b128 (lane t reads row t) bank-conflict free without padding.
+__device__ __forceinline__ uint32_t tile_image_dword(uint32_t row, uint32_t c) {
+    return row * kThreadDwords + ((((c >> 2) ^ (row >> 2)) & 3u) << 2) + (c & 3u);
+}
+
 // ---------------------------------------------------------------------------------------------
-// histogram: counts[d][tile] = number of keys of `tile` whose digit is d
-// (what shaders-sdk/radix/counting.comp:49-116 leaves in counts[g][r], per tile instead of per
-// 108th of the input).  LDS bins are replicated 32x so that lane l only ever touches bank l&31:
-// no bank conflict and no same-address serialisation however skewed the digits are.
+// histogram: counts[g][d] = number of keys of tile g whose digit is d
+// (shaders-sdk/radix/counting.comp:49-116).  Runs for the first pass of a sort only.  LDS bins
+// are replicated 32x so that lane l only ever touches bank l&31: no bank conflict and no
+// same-address serialisation however skewed the digits are.
 // ---------------------------------------------------------------------------------------------
 template <typename K>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys, uint32_t n, int bit,
@@ -109,14 +129,14 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
     __shared__ uint32_t bins[kRadices * 32];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t tile = tile_of_block(blockIdx.x, num_tiles);
+    const uint32_t g = tile_of_workgroup(blockIdx.x, num_tiles);
     bins[tid] = 0u;
     bins[tid + kBlock] = 0u;
     __syncthreads();
 
-    const uint32_t base = tile * TILE;
-    const uint32_t valid = min(TILE, n - base);
     const uint32_t col = tid & 31u;
+    const uint32_t base = g * TILE;
+    const uint32_t valid = min(TILE, n - base);
     if (valid == TILE) {
         const uint4* src = reinterpret_cast<const uint4*>(keys + base);
         uint4 v[kThreadDwords / 4];
@@ -152,75 +172,83 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
     }
     if (col == 0u) {
         const uint32_t d = tid >> 5;
-        counts[static_cast<size_t>(d) * num_tiles + tile] = lo;
-        counts[static_cast<size_t>(d + 8u) * num_tiles + tile] = hi;
+        counts[static_cast<size_t>(g) * kRadices + d] = lo;
+        counts[static_cast<size_t>(g) * kRadices + d + 8u] = hi;
     }
 }
 
 // ---------------------------------------------------------------------------------------------
-// scan: exclusive prefix sum over the digit-major table, i.e. over (digit, tile) in that order —
-// the order shaders-sdk/radix/partition.comp:29-68 produces with its two phases.
-// Kernel 1 scans chunks of 2048 words and leaves each chunk's total; kernel 2 (one workgroup)
-// scans the totals.  The scatter kernel adds the two.
+// scan: partitions[g][r] = sum_{r' < r} total[r'] + sum_{g' < g} counts[g'][r], the exclusive scan
+// in (radix, workgroup) order that shaders-sdk/radix/partition.comp:29-68 produces in two phases.
+// Kernel 1: every scan workgroup takes 256 consecutive table rows (one per thread) and scans each
+// of the 16 radix columns across them, leaving the column totals.  Kernel 2 (one workgroup) scans
+// those totals in (radix, scan-workgroup) order.  The scatter kernel adds the two parts.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void scan_chunks_kernel(const uint32_t* __restrict__ counts,
-                                                              uint32_t* __restrict__ offsets,
-                                                              uint32_t* __restrict__ chunk_sums,
-                                                              uint32_t len) {
-    __shared__ uint32_t wave_tot[kBlock / 64];
+__global__ __launch_bounds__(kBlock) void scan_rows_kernel(const uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ offsets,
+                                                            uint32_t* __restrict__ group_sums,
+                                                            uint32_t num_tiles) {
+    __shared__ uint32_t wave_tot[kBlock / 64][kRadices];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t base = blockIdx.x * kScanChunk + tid * 8u;
-    uint32_t v[8];
-    if (base + 8u <= len) {
-        const uint4 a = *reinterpret_cast<const uint4*>(counts + base);
-        const uint4 b = *reinterpret_cast<const uint4*>(counts + base + 4);
-        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w;
-        v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    const uint32_t row = blockIdx.x * kScanBlocks + tid;
+    uint32_t v[kRadices];
+    if (row < num_tiles) {
+        const uint4* src = reinterpret_cast<const uint4*>(counts + static_cast<size_t>(row) * kRadices);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const uint4 a = src[q];
+            v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+        }
     } else {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = (base + i < len) ? counts[base + i] : 0u;
+        for (int d = 0; d < kRadices; ++d) v[d] = 0u;
     }
-    uint32_t total = 0;
+    uint32_t incl[kRadices];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) total += v[i];
-    const uint32_t incl = wave_inclusive_scan(total, lane);
-    if (lane == 63u) wave_tot[wave] = incl;
+    for (int d = 0; d < kRadices; ++d) incl[d] = wave_inclusive_scan(v[d]);
+    if (lane == 63u) {
+#pragma unroll
+        for (int d = 0; d < kRadices; ++d) wave_tot[wave][d] = incl[d];
+    }
     __syncthreads();
-    uint32_t before = 0, all = 0;
+    uint32_t o[kRadices];
 #pragma unroll
-    for (int w = 0; w < kBlock / 64; ++w) {
-        const uint32_t t = wave_tot[w];
-        if (static_cast<uint32_t>(w) < wave) before += t;
-        all += t;
+    for (int d = 0; d < kRadices; ++d) {
+        uint32_t before = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w)
+            if (static_cast<uint32_t>(w) < wave) before += wave_tot[w][d];
+        o[d] = incl[d] - v[d] + before;
     }
-    uint32_t run = incl - total + before;
-    uint32_t o[8];
+    if (row < num_tiles) {
+        uint4* dst = reinterpret_cast<uint4*>(offsets + static_cast<size_t>(row) * kRadices);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { o[i] = run; run += v[i]; }
-    if (base + 8u <= len) {
-        *reinterpret_cast<uint4*>(offsets + base) = make_uint4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<uint4*>(offsets + base + 4) = make_uint4(o[4], o[5], o[6], o[7]);
-    } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) if (base + i < len) offsets[base + i] = o[i];
+        for (int q = 0; q < 4; ++q) dst[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
     }
-    if (tid == 0u) chunk_sums[blockIdx.x] = all;
+    if (tid < static_cast<uint32_t>(kRadices)) {
+        uint32_t all = 0;
+#pragma unroll
+        for (int w = 0; w < kBlock / 64; ++w) all += wave_tot[w][tid];
+        group_sums[static_cast<size_t>(blockIdx.x) * kRadices + tid] = all;
+    }
 }
 
-__global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ chunk_sums,
-                                                          uint32_t num_chunks,
-                                                          const uint32_t* __restrict__ offsets,
-                                                          uint32_t num_tiles, uint32_t n,
-                                                          uint32_t* __restrict__ digit_starts) {
+// group_sums[j][d] -> exclusive scan over the linear order L = d * num_groups + j, in place.
+__global__ __launch_bounds__(1024) void scan_groups_kernel(uint32_t* __restrict__ group_sums,
+                                                            uint32_t num_groups, uint32_t n,
+                                                            uint32_t* __restrict__ digit_starts) {
     __shared__ uint32_t wave_tot[16];
     __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t len = num_groups * kRadices;
     if (tid == 0u) carry_s = 0u;
     __syncthreads();
-    for (uint32_t start = 0; start < num_chunks; start += 1024u) {
-        const uint32_t i = start + tid;
-        const uint32_t v = i < num_chunks ? chunk_sums[i] : 0u;
-        const uint32_t incl = wave_inclusive_scan(v, lane);
+    for (uint32_t start = 0; start < len; start += 1024u) {
+        const uint32_t L = start + tid;
+        const uint32_t d = L / num_groups, j = L - d * num_groups;
+        const size_t at = static_cast<size_t>(j) * kRadices + d;
+        const uint32_t v = L < len ? group_sums[at] : 0u;
+        const uint32_t incl = wave_inclusive_scan(v);
         if (lane == 63u) wave_tot[wave] = incl;
         __syncthreads();
         uint32_t before = 0, all = 0;
@@ -231,63 +259,71 @@ __global__ __launch_bounds__(1024) void scan_sums_kernel(uint32_t* __restrict__ 
             all += t;
         }
         const uint32_t carry = carry_s;
-        if (i < num_chunks) chunk_sums[i] = carry + before + incl - v;
+        const uint32_t excl = carry + before + incl - v;
+        // Reads of this round happened before the barrier above and every word is read and
+        // written by the same thread, so the in-place update is safe.
+        if (L < len) {
+            group_sums[at] = excl;
+            if (j == 0u) digit_starts[d] = excl;  // start of every digit's output run
+        }
         __syncthreads();
         if (tid == 0u) carry_s = carry + all;
         __syncthreads();
     }
-    // Start of every digit's output run, for callers that split by digit (multi-GPU exchange).
-    __threadfence_block();
-    __syncthreads();
-    if (tid < static_cast<uint32_t>(kRadices)) {
-        const uint32_t idx = tid * num_tiles;
-        digit_starts[tid] = offsets[idx] + chunk_sums[idx / kScanChunk];
-    }
-    if (tid == static_cast<uint32_t>(kRadices)) digit_starts[kRadices] = n;
+    if (tid == 0u) digit_starts[kRadices] = n;
 }
 
 // ---------------------------------------------------------------------------------------------
-// scatter: stable partition of one tile by digit, written to offsets[d][tile] + rank
+// scatter: stable partition of one tile by digit, written to partitions[g][d] + rank
 // (shaders-sdk/radix/scattering.comp:57-149; out index = localPartitions[d] + earlier keys of
 // digit d in address order, :141-143).
 //
-//   1. coalesced 16-B loads, transposed through LDS so thread t holds the tile's keys
-//      [t*KPT, (t+1)*KPT) — consecutive in address order (rows padded 16->20 dwords);
+//   1. coalesced 16-B loads, passed through an XOR-swizzled LDS image so thread t holds the
+//      tile's keys [t*KPT, (t+1)*KPT) — consecutive in address order;
 //   2. per key one returning LDS add on the thread's own packed counter: the old value is the
 //      key's rank among the thread's earlier keys of that digit;
 //   3. one block-wide exclusive scan over the 8x256 packed counters in (row, thread) order, the
 //      low-half grand total carried into the high halves: counter (d, t) becomes the number of
 //      tile keys that sort before thread t's first key of digit d;
 //   4. keys go to LDS at their tile rank and come back in rank order, so lane l of a store
-//      instruction writes run position s = m*256 + l: consecutive lanes, consecutive addresses.
+//      instruction writes run position s = m*256 + l: consecutive lanes, consecutive addresses;
+//   5. FUSE: every stored key adds 1 to an LDS counter for (its digit, its next-pass digit).
+//      Counters for keys landing in the first destination tile of their digit's run are 8 bits
+//      wide, 4 to a word, and replicated over 32 columns so that lane l only touches bank l&31
+//      (a column sees at most 128 keys, so a byte never overflows); the counter words reuse the
+//      rank counters' LDS, which is dead by then.  Keys landing in the run's second destination
+//      tile (a run crosses at most one tile boundary) are rare and use a plain 16x16 table.
+//      After the last store the sums are added to next_counts[destination tile][next digit].
 // ---------------------------------------------------------------------------------------------
-template <typename K, bool HAS_V>
+template <typename K, bool HAS_V, bool FUSE>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* __restrict__ vin,
     uint32_t* __restrict__ vout, uint32_t n, int bit, uint32_t mask,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ chunk_sums,
-    uint32_t num_tiles) {
+    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ group_sums,
+    uint32_t num_tiles, int next_bit, uint32_t next_mask, uint32_t* __restrict__ next_counts) {
     constexpr int KPT = KeyTraits<K>::kpt;
+    constexpr int LOG_TILE = KeyTraits<K>::log_tile;
     constexpr uint32_t TILE = kBlock * KPT;
     constexpr int PER_VEC = 16 / sizeof(K);
     constexpr int NVEC = kThreadDwords / 4;
+    constexpr int KEY_DWORDS = sizeof(K) / 4;
 
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kBlock * kRowStride];
-    __shared__ __attribute__((aligned(16))) uint32_t ctr[kCtrRows * kBlock];
-    __shared__ uint32_t delta[kRadices];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[kTileDwords];
+    __shared__ __attribute__((aligned(16))) uint32_t ctr[kCtrRows * kBlock];  // FUSE: reused as next_first[64][32]
+    __shared__ uint32_t next_second[FUSE ? kRadices * kRadices : 1];
+    __shared__ __attribute__((aligned(8))) uint2 where_s[kRadices];  // .x = global base - tile start of the digit, .y = its first destination tile
     __shared__ uint32_t wave_tot[kBlock / 64];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t tile = tile_of_block(blockIdx.x, num_tiles);
-    const uint32_t base = tile * TILE;
+    const uint32_t g = tile_of_workgroup(blockIdx.x, num_tiles);
+    const uint32_t base = g * TILE;
     const uint32_t valid = min(TILE, n - base);
 
     // Global output base of every digit for this tile; issued first, consumed after the scan.
-    uint32_t gbase = 0;
-    if (tid < static_cast<uint32_t>(kRadices)) {
-        const uint32_t idx = tid * num_tiles + tile;
-        gbase = offsets[idx] + chunk_sums[idx / kScanChunk];
-    }
+    uint32_t run_base = 0;
+    if (tid < static_cast<uint32_t>(kRadices))
+        run_base = offsets[static_cast<size_t>(g) * kRadices + tid] +
+                   group_sums[static_cast<size_t>(g / kScanBlocks) * kRadices + tid];
 
     K key[KPT];
     uint32_t val[HAS_V ? KPT : 1];
@@ -307,21 +343,28 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
 #pragma unroll
         for (int m = 0; m < NVEC; ++m) {
             const uint32_t row = m * (kBlock / 4) + (tid >> 2);
-            *reinterpret_cast<uint4*>(&stage[row * kRowStride + 4u * (tid & 3u)]) = v[m];
-        }
-        __syncthreads();
-#pragma unroll
-        for (int m = 0; m < NVEC; ++m) {
-            const uint4 q = *reinterpret_cast<const uint4*>(&stage[tid * kRowStride + 4 * m]);
-            unpack4<K>(q, &key[m * PER_VEC]);
+            *reinterpret_cast<uint4*>(&stage[tile_image_dword(row, 4u * (tid & 3u))]) = v[m];
         }
     } else {
-#pragma unroll
-        for (int i = 0; i < KPT; ++i) {
-            const uint32_t idx = tid * KPT + i;
-            key[i] = idx < valid ? kin[base + idx] : static_cast<K>(~static_cast<K>(0));
-            if (HAS_V) val[i] = idx < valid ? vin[base + idx] : 0u;
+        // ragged last tile of the input: element-wise loads into the same LDS image, all-ones
+        // keys past the end (they take the highest ranks of the last digit and are not stored)
+#pragma unroll 1
+        for (uint32_t e = tid; e < TILE; e += kBlock) {
+            const K k = e < valid ? kin[base + e] : static_cast<K>(~static_cast<K>(0));
+            const uint32_t at = tile_image_dword(e / KPT, (e % KPT) * KEY_DWORDS);
+            stage[at] = static_cast<uint32_t>(k);
+            if (KEY_DWORDS == 2) stage[at + 1] = static_cast<uint32_t>(static_cast<uint64_t>(k) >> 32);
         }
+        if (HAS_V) {
+#pragma unroll
+            for (int i = 0; i < KPT; ++i) val[i] = vin[base + min(tid * KPT + i, valid - 1u)];
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NVEC; ++m) {
+        const uint4 q = *reinterpret_cast<const uint4*>(&stage[tile_image_dword(tid, 4u * m)]);
+        unpack4<K>(q, &key[m * PER_VEC]);
     }
 
     // 2. thread-private packed counters.
@@ -346,7 +389,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         uint32_t total = 0;
 #pragma unroll
         for (int i = 0; i < 8; ++i) total += c[i];
-        const uint32_t incl = wave_inclusive_scan(total, lane);
+        const uint32_t incl = wave_inclusive_scan(total);
         if (lane == 63u) wave_tot[wave] = incl;
         __syncthreads();
         uint32_t before = 0, all = 0;
@@ -366,7 +409,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     }
     __syncthreads();
 
-    // 4. tile ranks; digit d's run starts at the counter of (d, thread 0).
+    // 4. tile ranks; digit d's tile run starts at the counter of (d, thread 0).
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t d = digit_of<K>(key[i], bit, mask);
@@ -375,22 +418,68 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     }
     if (tid < static_cast<uint32_t>(kRadices)) {
         const uint32_t start = (ctr[(tid & 7u) * kBlock] >> ((tid >> 3) << 4)) & 0xffffu;
-        delta[tid] = gbase - start;
+        where_s[tid] = make_uint2(run_base - start, run_base >> LOG_TILE);
     }
     K* skeys = reinterpret_cast<K*>(stage);
 #pragma unroll
     for (int i = 0; i < KPT; ++i) skeys[rank[i]] = key[i];
     __syncthreads();
 
+    if (FUSE) {
+        // the rank counters are dead: their words become the zeroed next-pass counters
+        *reinterpret_cast<uint4*>(&ctr[tid * 8u]) = make_uint4(0u, 0u, 0u, 0u);
+        *reinterpret_cast<uint4*>(&ctr[tid * 8u + 4u]) = make_uint4(0u, 0u, 0u, 0u);
+        next_second[tid] = 0u;
+        __syncthreads();
+    }
+
     uint32_t dst[HAS_V ? KPT : 1];
+    const uint32_t col = tid & 31u;
 #pragma unroll
     for (int m = 0; m < KPT; ++m) {
         const uint32_t s = m * kBlock + tid;
         const K k = skeys[s];
-        const uint32_t where = delta[digit_of<K>(k, bit, mask)] + s;
+        const uint32_t d = digit_of<K>(k, bit, mask);
+        const uint2 w = where_s[d];
+        const uint32_t where = w.x + s;
         if (HAS_V) dst[m] = where;
-        if (s < valid) kout[where] = k;
+        if (s < valid) {
+            kout[where] = k;
+            if (FUSE) {
+                const uint32_t d2 = digit_of<K>(k, next_bit, next_mask);
+                const uint32_t slot = (d << 4) | d2;
+                if ((where >> LOG_TILE) == w.y)
+                    __hip_atomic_fetch_add(&ctr[(slot >> 2) * 32u + col], 1u << ((slot & 3u) << 3),
+                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                else
+                    __hip_atomic_fetch_add(&next_second[slot], 1u, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
     }
+
+    if (FUSE) {
+        __syncthreads();
+        // Thread t sums columns 8*(t&3)..+7 of counter row t>>2 (slots 4*(t>>2)..+3, one per byte),
+        // widening bytes to 16-bit fields first; the 4 threads of a row then combine, and thread t
+        // keeps the sum of slot t = (digit t>>4, next digit t&15).
+        const uint4 a = *reinterpret_cast<const uint4*>(&ctr[tid * 8u]);
+        const uint4 b = *reinterpret_cast<const uint4*>(&ctr[tid * 8u + 4u]);
+        const uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        uint32_t even = 0, odd = 0;  // even: slots +0 (low 16) and +2 (high 16); odd: slots +1 and +3
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { even += c[i] & 0x00ff00ffu; odd += (c[i] >> 8) & 0x00ff00ffu; }
+        even += __shfl_xor(even, 1, 64); odd += __shfl_xor(odd, 1, 64);
+        even += __shfl_xor(even, 2, 64); odd += __shfl_xor(odd, 2, 64);
+        const uint32_t pick = (tid & 1u) ? odd : even;
+        const uint32_t first_sum = (tid & 2u) ? pick >> 16 : pick & 0xffffu;
+        const uint32_t second_sum = next_second[tid];
+        const uint32_t dest = where_s[tid >> 4].y;
+        uint32_t* row = next_counts + static_cast<size_t>(dest) * kRadices + (tid & 15u);
+        if (first_sum) atomicAdd(row, first_sum);
+        if (second_sum) atomicAdd(row + kRadices, second_sum);
+    }
+
     if (HAS_V) {
         __syncthreads();
 #pragma unroll
@@ -495,25 +584,35 @@ int bad_arg(const char* what) {
 
 constexpr uint64_t kMaxElements = 0xffffffffull;  // element indices are 32-bit, as in the reference
 
-uint32_t tile_keys(int key_bytes) { return static_cast<uint32_t>(kTileDwords * 4 / key_bytes); }
-uint32_t tiles_for(uint64_t n, int key_bytes) {
-    const uint64_t t = tile_keys(key_bytes);
-    return static_cast<uint32_t>((n + t - 1) / t);
+// get_blocks_info (shaders-sdk/radix/includes.glsl:162-173) with grid = ceil(n / tile): every
+// workgroup's chunk is one tile.
+struct Geometry {
+    uint32_t tile;        // keys per tile (16 KiB of keys)
+    uint32_t num_tiles;   // grid
+    uint32_t num_groups;  // scan workgroups: ceil(num_tiles / 256)
+};
+Geometry geometry_for(uint64_t n, int key_bytes) {
+    Geometry g;
+    g.tile = static_cast<uint32_t>(kTileDwords * 4 / key_bytes);
+    const uint64_t nn = n ? n : 1;
+    g.num_tiles = static_cast<uint32_t>((nn + g.tile - 1) / g.tile);
+    g.num_groups = (g.num_tiles + kScanBlocks - 1) / kScanBlocks;
+    return g;
 }
 size_t align256(size_t b) { return (b + 255u) & ~static_cast<size_t>(255u); }
 
 struct ScratchLayout {
-    size_t counts, offsets, chunk_sums, digit_starts, total;
+    size_t counts[2], offsets, group_sums, digit_starts, total;
 };
 ScratchLayout layout_for(uint64_t max_n, int key_bytes) {
-    const size_t tiles = tiles_for(max_n ? max_n : 1, key_bytes);
-    const size_t words = tiles * kRadices;
-    const size_t chunks = (words + kScanChunk - 1) / kScanChunk;
+    const Geometry g = geometry_for(max_n, key_bytes);
+    const size_t table = align256(static_cast<size_t>(g.num_tiles) * kRadices * 4);
     ScratchLayout l;
-    l.counts = 0;
-    l.offsets = l.counts + align256(words * 4);
-    l.chunk_sums = l.offsets + align256(words * 4);
-    l.digit_starts = l.chunk_sums + align256(chunks * 4);
+    l.counts[0] = 0;
+    l.counts[1] = table;
+    l.offsets = 2 * table;
+    l.group_sums = 3 * table;
+    l.digit_starts = l.group_sums + align256(static_cast<size_t>(g.num_groups) * kRadices * 4);
     l.total = l.digit_starts + align256(32 * 4);
     return l;
 }
@@ -544,12 +643,17 @@ struct radx_hip_sorter {
     uint64_t max_n = 0;
     int key_bytes = 4;
     int value_bytes = 0;
+    bool fuse = true;
     char* scratch = nullptr;
     ScratchLayout layout{};
-    uint32_t* counts = nullptr;
+    uint32_t* counts[2] = {nullptr, nullptr};
     uint32_t* offsets = nullptr;
-    uint32_t* chunk_sums = nullptr;
+    uint32_t* group_sums = nullptr;
     uint32_t* digit_starts = nullptr;
+    int cur = 0;            // counts[cur] holds the histogram of the last pass run
+    bool chained = false;   // counts[cur ^ 1] holds a fused histogram for the next pass
+    uint64_t chained_n = 0;
+    int chained_bit = 0, chained_bits = 0;
     bool profile = false;
     std::vector<Timed> pending;
     std::vector<Timed> pool;
@@ -581,44 +685,67 @@ private:
     bool active_ = false;
 };
 
+struct PassArgs {
+    const void* kin; void* kout; const void* vin; void* vout;
+    uint32_t n;
+    int bit, num_bits;            // this pass's digit
+    bool have_counts;             // counts[cur ^ 1] already holds this pass's histogram (fused by the previous pass)
+    bool fuse_next;               // accumulate the next pass's histogram while scattering
+    int next_bit, next_num_bits;  // the next pass's digit
+};
+
 template <typename K, bool HAS_V>
-int run_pass_typed(radx_hip_sorter* s, const void* kin, void* kout, const void* vin, void* vout,
-                   uint32_t n, int bit, int num_bits, hipStream_t stream) {
-    const uint32_t tiles = tiles_for(n, sizeof(K));
-    const uint32_t words = tiles * kRadices;
-    const uint32_t chunks = (words + kScanChunk - 1) / kScanChunk;
-    const uint32_t mask = (1u << num_bits) - 1u;
-    {
+int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
+    const Geometry g = geometry_for(a.n, sizeof(K));
+    const uint32_t mask = (1u << a.num_bits) - 1u;
+    const uint32_t next_mask = (1u << a.next_num_bits) - 1u;
+    const size_t table_bytes = static_cast<size_t>(g.num_tiles) * kRadices * 4;
+    const K* kin = static_cast<const K*>(a.kin);
+    K* kout = static_cast<K*>(a.kout);
+    const uint32_t* vin = static_cast<const uint32_t*>(a.vin);
+    uint32_t* vout = static_cast<uint32_t*>(a.vout);
+
+    if (a.have_counts) {
+        s->cur ^= 1;  // the table the previous scatter filled becomes this pass's histogram
+    } else {
         LaunchTimer t(s, 0, stream);
-        hipLaunchKernelGGL(hist_kernel<K>, dim3(tiles), dim3(kBlock), 0, stream,
-                           static_cast<const K*>(kin), n, bit, mask, s->counts, tiles);
+        hipLaunchKernelGGL(hist_kernel<K>, dim3(g.num_tiles), dim3(kBlock), 0, stream, kin, a.n, a.bit,
+                           mask, s->counts[s->cur], g.num_tiles);
     }
+    uint32_t* counts = s->counts[s->cur];
+    uint32_t* next_counts = s->counts[s->cur ^ 1];
     {
         LaunchTimer t(s, 1, stream);
-        hipLaunchKernelGGL(scan_chunks_kernel, dim3(chunks), dim3(kBlock), 0, stream, s->counts,
-                           s->offsets, s->chunk_sums, words);
-        hipLaunchKernelGGL(scan_sums_kernel, dim3(1), dim3(1024), 0, stream, s->chunk_sums, chunks,
-                           s->offsets, tiles, n, s->digit_starts);
+        if (a.fuse_next) RADX_TRY(hipMemsetAsync(next_counts, 0, table_bytes, stream));
+        hipLaunchKernelGGL(scan_rows_kernel, dim3(g.num_groups), dim3(kBlock), 0, stream, counts, s->offsets,
+                           s->group_sums, g.num_tiles);
+        hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, stream, s->group_sums, g.num_groups,
+                           a.n, s->digit_starts);
     }
     {
         LaunchTimer t(s, 2, stream);
-        hipLaunchKernelGGL((scatter_kernel<K, HAS_V>), dim3(tiles), dim3(kBlock), 0, stream,
-                           static_cast<const K*>(kin), static_cast<K*>(kout),
-                           static_cast<const uint32_t*>(vin), static_cast<uint32_t*>(vout), n, bit,
-                           mask, s->offsets, s->chunk_sums, tiles);
+        if (a.fuse_next)
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true>), dim3(g.num_tiles), dim3(kBlock), 0, stream,
+                               kin, kout, vin, vout, a.n, a.bit, mask, s->offsets, s->group_sums, g.num_tiles,
+                               a.next_bit, next_mask, next_counts);
+        else
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false>), dim3(g.num_tiles), dim3(kBlock), 0, stream,
+                               kin, kout, vin, vout, a.n, a.bit, mask, s->offsets, s->group_sums, g.num_tiles,
+                               0, 0u, static_cast<uint32_t*>(nullptr));
     }
     RADX_TRY(hipGetLastError());
+    s->chained = a.fuse_next;
+    s->chained_n = a.n;
+    s->chained_bit = a.next_bit;
+    s->chained_bits = a.next_num_bits;
     return 0;
 }
 
-int run_pass(radx_hip_sorter* s, const void* kin, void* kout, const void* vin, void* vout, uint32_t n,
-             int bit, int num_bits, hipStream_t stream) {
+int run_pass(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
     const bool has_v = s->value_bytes != 0;
     if (s->key_bytes == 4)
-        return has_v ? run_pass_typed<uint32_t, true>(s, kin, kout, vin, vout, n, bit, num_bits, stream)
-                     : run_pass_typed<uint32_t, false>(s, kin, kout, vin, vout, n, bit, num_bits, stream);
-    return has_v ? run_pass_typed<uint64_t, true>(s, kin, kout, vin, vout, n, bit, num_bits, stream)
-                 : run_pass_typed<uint64_t, false>(s, kin, kout, vin, vout, n, bit, num_bits, stream);
+        return has_v ? run_pass_typed<uint32_t, true>(s, a, stream) : run_pass_typed<uint32_t, false>(s, a, stream);
+    return has_v ? run_pass_typed<uint64_t, true>(s, a, stream) : run_pass_typed<uint64_t, false>(s, a, stream);
 }
 
 bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
@@ -641,11 +768,17 @@ int check_buffers(const radx_hip_sorter* s, const void* k0, const void* k1, cons
     return 0;
 }
 
+int check_digit(const radx_hip_sorter* s, int bit, int num_bits) {
+    if (num_bits < 0 || num_bits > kDigitBits) return bad_arg("num_bits must be 0..4");
+    if (bit < 0 || bit + num_bits > s->key_bytes * 8) return bad_arg("digit outside the key");
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
 
-int radx_hip_version(void) { return 100; }
+int radx_hip_version(void) { return 300; }
 
 const char* radx_hip_error_string(void) { return g_error; }
 
@@ -675,9 +808,10 @@ int radx_hip_create(int device, uint64_t max_n, int key_bytes, int value_bytes, 
     s->layout = layout_for(max_n, key_bytes);
     const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->scratch), s->layout.total);
     if (e != hipSuccess) { delete s; return fail(e, "hipMalloc(scratch)"); }
-    s->counts = reinterpret_cast<uint32_t*>(s->scratch + s->layout.counts);
+    s->counts[0] = reinterpret_cast<uint32_t*>(s->scratch + s->layout.counts[0]);
+    s->counts[1] = reinterpret_cast<uint32_t*>(s->scratch + s->layout.counts[1]);
     s->offsets = reinterpret_cast<uint32_t*>(s->scratch + s->layout.offsets);
-    s->chunk_sums = reinterpret_cast<uint32_t*>(s->scratch + s->layout.chunk_sums);
+    s->group_sums = reinterpret_cast<uint32_t*>(s->scratch + s->layout.group_sums);
     s->digit_starts = reinterpret_cast<uint32_t*>(s->scratch + s->layout.digit_starts);
     *out = s;
     return 0;
@@ -694,16 +828,33 @@ int radx_hip_destroy(radx_hip_sorter* s) {
     return 0;
 }
 
+int radx_hip_tune(radx_hip_sorter* s, int fuse_histogram) {
+    if (!s) return bad_arg("sorter is NULL");
+    s->fuse = fuse_histogram != 0;
+    s->chained = false;
+    return 0;
+}
+
 int radx_hip_pass(radx_hip_sorter* s, const void* keys_in, void* keys_out, const void* vals_in,
                   void* vals_out, uint64_t n, int bit, int num_bits, void* stream) {
+    return radx_hip_pass_fused(s, keys_in, keys_out, vals_in, vals_out, n, bit, num_bits, -1, 0, 0, stream);
+}
+
+int radx_hip_pass_fused(radx_hip_sorter* s, const void* keys_in, void* keys_out, const void* vals_in,
+                        void* vals_out, uint64_t n, int bit, int num_bits, int next_bit, int next_num_bits,
+                        int use_fused_counts, void* stream) {
     if (const int rc = check_buffers(s, keys_in, keys_out, vals_in, vals_out, n)) return rc;
-    if (num_bits < 0 || num_bits > kDigitBits) return bad_arg("num_bits must be 0..4");
-    if (bit < 0 || bit + num_bits > s->key_bytes * 8) return bad_arg("digit outside the key");
+    if (const int rc = check_digit(s, bit, num_bits)) return rc;
+    const bool fuse_next = next_bit >= 0;
+    if (fuse_next) if (const int rc = check_digit(s, next_bit, next_num_bits)) return rc;
+    if (use_fused_counts && !(s->chained && s->chained_n == n && s->chained_bit == bit && s->chained_bits == num_bits))
+        return bad_arg("no fused histogram for this digit and n: the previous pass did not produce one");
     if (n == 0) return 0;
     DeviceGuard guard(s->device);
     RADX_TRY(guard.status());
-    return run_pass(s, keys_in, keys_out, vals_in, vals_out, static_cast<uint32_t>(n), bit, num_bits,
-                    static_cast<hipStream_t>(stream));
+    PassArgs a{keys_in, keys_out, vals_in, vals_out, static_cast<uint32_t>(n), bit, num_bits,
+               use_fused_counts != 0, fuse_next, fuse_next ? next_bit : 0, fuse_next ? next_num_bits : 0};
+    return run_pass(s, a, static_cast<hipStream_t>(stream));
 }
 
 int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, void* vals_swap,
@@ -718,16 +869,24 @@ int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* va
     passes += passes & 1;  // even, so the result ends in `keys` (scattering.comp:40,143)
     void* kbuf[2] = {keys, keys_swap};
     void* vbuf[2] = {vals, vals_swap};
+    auto digit_at = [&](int p, int* bit, int* width) {
+        int b = begin_bit + p * kDigitBits, w = end_bit - b;
+        if (w > kDigitBits) w = kDigitBits;
+        if (w <= 0) { w = 0; b = 0; }  // padding pass: zero-width digit, a stable copy
+        *bit = b; *width = w;
+    };
     for (int p = 0; p < passes; ++p) {
-        const int bit = begin_bit + p * kDigitBits;
-        int width = end_bit - bit;
-        if (width > kDigitBits) width = kDigitBits;
-        if (width < 0) width = 0;
+        PassArgs a{};
+        digit_at(p, &a.bit, &a.num_bits);
         const int src = p & 1, dstb = 1 - src;
-        const int rc = run_pass(s, kbuf[src], kbuf[dstb], vbuf[src], vbuf[dstb], static_cast<uint32_t>(n),
-                                width ? bit : 0, width, static_cast<hipStream_t>(stream));
-        if (rc) return rc;
+        a.kin = kbuf[src]; a.kout = kbuf[dstb]; a.vin = vbuf[src]; a.vout = vbuf[dstb];
+        a.n = static_cast<uint32_t>(n);
+        a.have_counts = s->fuse && p > 0;
+        a.fuse_next = s->fuse && p + 1 < passes;
+        if (a.fuse_next) digit_at(p + 1, &a.next_bit, &a.next_num_bits);
+        if (const int rc = run_pass(s, a, static_cast<hipStream_t>(stream))) return rc;
     }
+    s->chained = false;
     return 0;
 }
 
@@ -737,11 +896,12 @@ int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, v
     return radx_hip_sort_bits(s, keys, keys_swap, vals, vals_swap, n, 0, s->key_bytes * 8, stream);
 }
 
-int radx_hip_geometry(const radx_hip_sorter* s, uint64_t n, uint32_t* tile, uint32_t* num_tiles) {
+int radx_hip_geometry(const radx_hip_sorter* s, uint64_t n, uint32_t* tile_keys, uint32_t* num_tiles) {
     if (!s) return bad_arg("sorter is NULL");
     if (n > kMaxElements) return bad_arg("n must be < 2^32");
-    if (tile) *tile = tile_keys(s->key_bytes);
-    if (num_tiles) *num_tiles = tiles_for(n, s->key_bytes);
+    const Geometry g = geometry_for(n, s->key_bytes);
+    if (tile_keys) *tile_keys = g.tile;
+    if (num_tiles) *num_tiles = g.num_tiles;
     return 0;
 }
 
@@ -751,16 +911,16 @@ int radx_hip_copy_tables(radx_hip_sorter* s, uint64_t n, uint32_t* counts, uint3
     DeviceGuard guard(s->device);
     RADX_TRY(guard.status());
     hipStream_t st = static_cast<hipStream_t>(stream);
-    const uint32_t tiles = tiles_for(n, s->key_bytes);
-    const size_t words = static_cast<size_t>(tiles) * kRadices;
-    const size_t chunks = (words + kScanChunk - 1) / kScanChunk;
+    const Geometry g = geometry_for(n, s->key_bytes);
+    const size_t words = static_cast<size_t>(g.num_tiles) * kRadices;
     RADX_TRY(hipStreamSynchronize(st));
-    if (counts) RADX_TRY(hipMemcpy(counts, s->counts, words * 4, hipMemcpyDeviceToHost));
+    if (counts) RADX_TRY(hipMemcpy(counts, s->counts[s->cur], words * 4, hipMemcpyDeviceToHost));
     if (offsets) {
-        std::vector<uint32_t> sums(chunks);
+        std::vector<uint32_t> sums(static_cast<size_t>(g.num_groups) * kRadices);
         RADX_TRY(hipMemcpy(offsets, s->offsets, words * 4, hipMemcpyDeviceToHost));
-        RADX_TRY(hipMemcpy(sums.data(), s->chunk_sums, chunks * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < words; ++i) offsets[i] += sums[i / kScanChunk];
+        RADX_TRY(hipMemcpy(sums.data(), s->group_sums, sums.size() * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < words; ++i)
+            offsets[i] += sums[(i / kRadices / kScanBlocks) * kRadices + (i % kRadices)];
     }
     return 0;
 }

@@ -82,16 +82,29 @@ class Sorter:
         capi.check(capi.lib.radx_hip_pass(self._h, _ptr(keys_in), _ptr(keys_out), _ptr(vals_in),
                                           _ptr(vals_out), n, bit, num_bits, _stream(stream, self.device)))
 
+    def run_pass_fused(self, keys_in, keys_out, bit, num_bits, next_bit, next_num_bits, use_fused_counts,
+                       vals_in=None, vals_out=None, n=None, stream=None):
+        """One pass as sort() chains them: optionally take the histogram the previous fused pass
+        accumulated, and accumulate the next pass's histogram (next_bit < 0: do not)."""
+        n = self._args(keys_in, keys_out, vals_in, vals_out, n)
+        capi.check(capi.lib.radx_hip_pass_fused(self._h, _ptr(keys_in), _ptr(keys_out), _ptr(vals_in),
+                                                _ptr(vals_out), n, bit, num_bits, next_bit, next_num_bits,
+                                                1 if use_fused_counts else 0, _stream(stream, self.device)))
+
+    def tune(self, fuse_histogram=True):
+        capi.check(capi.lib.radx_hip_tune(self._h, 1 if fuse_histogram else 0))
+
     def geometry(self, n):
+        """(keys per tile, number of tiles) for n elements; one workgroup per tile."""
         tile, tiles = ctypes.c_uint32(0), ctypes.c_uint32(0)
         capi.check(capi.lib.radx_hip_geometry(self._h, int(n), ctypes.byref(tile), ctypes.byref(tiles)))
         return tile.value, tiles.value
 
     def tables(self, n, stream=None):
-        """(counts, offsets) of the last pass as uint32 arrays of shape [16, num_tiles]."""
+        """(counts, offsets) of the last pass as uint32 arrays of shape [num_tiles, 16]."""
         _, tiles = self.geometry(n)
-        counts = np.empty((16, tiles), dtype=np.uint32)
-        offsets = np.empty((16, tiles), dtype=np.uint32)
+        counts = np.empty((tiles, 16), dtype=np.uint32)
+        offsets = np.empty((tiles, 16), dtype=np.uint32)
         capi.check(capi.lib.radx_hip_copy_tables(self._h, int(n), counts.ctypes.data_as(ctypes.c_void_p),
                                                  offsets.ctypes.data_as(ctypes.c_void_p),
                                                  _stream(stream, self.device)))

@@ -65,24 +65,38 @@ def test_distributions(device, dist, key_bytes):
     assert np.array_equal(got, oracle.stable_sort(keys))
 
 
-@pytest.mark.parametrize("n", [1000, 4096, 3 * 4096 + 17, 70000])
-def test_u32_every_pass_matches_oracle(device, n):
-    """Histogram table, scanned offsets table and scattered output after EACH pass."""
+def check_geometry(s, n, cfg):
+    """The engine's chunking is the reference's get_blocks_info for its grid (includes.glsl:162-173)."""
+    tile, tiles = s.geometry(n)
+    assert tile == cfg.wave * cfg.vec and tiles == cfg.grid
+    for g in (0, cfg.grid // 2, cfg.grid - 1):
+        b = oracle.ref.radx_ref_blocks_info(cfg, n, g)
+        assert b.offset == min(g * tile, n) and b.limit == min((g + 1) * tile, n) and b.count == 1
+
+
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("n", [1000, 4096, 3 * 4096 + 17, 70000, 16 * 4096 + 1])
+def test_u32_every_pass_matches_oracle(device, n, fused):
+    """Histogram table, scanned offsets table and scattered output after EACH pass — with the
+    histogram kernel every pass, and with the histogram accumulated by the previous scatter."""
     import torch
     import radx_amd
     keys = make_keys("hash", n, 4, seed=11)
     cfg = oracle.engine_config(n, 4)
     s = radx_amd.Sorter(n, 4, 0)
-    assert s.geometry(n) == (4096, cfg.grid)
+    check_geometry(s, n, cfg)
     cur = to_dev(keys, device)
     nxt = torch.empty_like(cur)
     host = keys
     for p in range(8):
-        s.run_pass(cur, nxt, bit=4 * p, num_bits=4)
+        if fused:
+            s.run_pass_fused(cur, nxt, 4 * p, 4, 4 * (p + 1) if p < 7 else -1, 4, use_fused_counts=p > 0)
+        else:
+            s.run_pass(cur, nxt, bit=4 * p, num_bits=4)
         counts, offsets = s.tables(n)
         c, part, out = oracle.one_pass(cfg, host, p)
-        assert np.array_equal(counts, c.T), "histogram table, pass %d" % p
-        assert np.array_equal(offsets, part.T), "offset table, pass %d" % p
+        assert np.array_equal(counts, c), "histogram table, pass %d" % p
+        assert np.array_equal(offsets, part), "offset table, pass %d" % p
         assert np.array_equal(to_host(nxt), out), "scattered keys, pass %d" % p
         starts = s.digit_starts()
         assert starts[16] == n and np.array_equal(starts[:16], part[0])
@@ -91,8 +105,9 @@ def test_u32_every_pass_matches_oracle(device, n):
     assert np.array_equal(host, np.sort(keys))
 
 
-@pytest.mark.parametrize("n", [777, 2048, 5 * 2048 + 9])
-def test_u64_kv_every_pass_matches_oracle(device, n):
+@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("n", [777, 2048, 5 * 2048 + 9, 9 * 2048 + 1])
+def test_u64_kv_every_pass_matches_oracle(device, n, fused):
     import torch
     import radx_amd
     keys = make_keys("few_distinct", n, 8, seed=13)
@@ -100,17 +115,55 @@ def test_u64_kv_every_pass_matches_oracle(device, n):
     vals = np.arange(n, dtype=np.uint32)
     cfg = oracle.engine_config(n, 8)
     s = radx_amd.Sorter(n, 8, 4)
-    assert s.geometry(n) == (2048, cfg.grid)
+    check_geometry(s, n, cfg)
     ck, cv = to_dev(keys, device), to_dev(vals, device)
     nk, nv = torch.empty_like(ck), torch.empty_like(cv)
     hk, hv = keys, vals
     for p in range(16):
-        s.run_pass(ck, nk, bit=4 * p, num_bits=4, vals_in=cv, vals_out=nv)
+        if fused:
+            s.run_pass_fused(ck, nk, 4 * p, 4, 4 * (p + 1) if p < 15 else -1, 4, use_fused_counts=p > 0,
+                             vals_in=cv, vals_out=nv)
+        else:
+            s.run_pass(ck, nk, bit=4 * p, num_bits=4, vals_in=cv, vals_out=nv)
         counts, offsets = s.tables(n)
         c, part, ok, ov = oracle.one_pass(cfg, hk, p, hv)
-        assert np.array_equal(counts, c.T) and np.array_equal(offsets, part.T), "tables, pass %d" % p
+        assert np.array_equal(counts, c) and np.array_equal(offsets, part), "tables, pass %d" % p
         assert np.array_equal(to_host(nk, 8), ok) and np.array_equal(to_host(nv, 4), ov), "pass %d" % p
         ck, nk, cv, nv, hk, hv = nk, ck, nv, cv, ok, ov
+    s.close()
+
+
+@pytest.mark.parametrize("dist", ["skewed", "all_equal", "sorted", "top_digit_only"])
+def test_fused_histogram_on_skewed_inputs(device, dist):
+    """Every scatter pass's accumulated next-pass histogram equals counting on its output, for
+    inputs whose digit runs are long (one run can fill whole destination blocks)."""
+    import torch
+    import radx_amd
+    n = 40 * 4096 + 333
+    keys = make_keys(dist, n, 4, seed=17)
+    cfg = oracle.engine_config(n, 4)
+    s = radx_amd.Sorter(n, 4, 0)
+    cur = to_dev(keys, device)
+    nxt = torch.empty_like(cur)
+    host = keys
+    for p in range(8):
+        s.run_pass_fused(cur, nxt, 4 * p, 4, 4 * (p + 1) if p < 7 else -1, 4, use_fused_counts=p > 0)
+        counts, offsets = s.tables(n)
+        c, part, out = oracle.one_pass(cfg, host, p)
+        assert np.array_equal(counts, c) and np.array_equal(offsets, part), "tables, pass %d" % p
+        assert np.array_equal(to_host(nxt), out), "scattered keys, pass %d" % p
+        cur, nxt, host = nxt, cur, out
+    s.close()
+
+
+@pytest.mark.parametrize("fuse", [False, True])
+def test_result_independent_of_tuning(device, fuse):
+    import radx_amd
+    n = 300007
+    keys = make_keys("uniform", n, 4, seed=8)
+    s = radx_amd.Sorter(n, 4, 0)
+    s.tune(fuse)
+    assert np.array_equal(gpu_sort(device, keys, sorter=s), np.sort(keys))
     s.close()
 
 

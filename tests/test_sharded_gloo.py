@@ -20,13 +20,11 @@ class OracleEngine:
 
     def split(self, src, dst, n, bit, num_bits):
         k = src[:n].numpy().view(np.uint32)
-        cfg = oracle.engine_config(n, 4, bits=4)
-        # one counting/partition/scattering pass on the digit (key >> bit) & (2^num_bits - 1)
+        # one counting/partition/scattering pass on the digit (key >> bit) & (2^num_bits - 1):
+        # single-workgroup geometry, whose partitions row is the start of every digit's run
+        cfg = oracle.Config(bits=4, grid=1, wave=64, vec=4)
         digit = (k >> np.uint32(bit)) & np.uint32((1 << num_bits) - 1)
-        counts = np.zeros((cfg.grid, 16), dtype=np.uint32)
-        tile = 4096
-        for g in range(cfg.grid):
-            counts[g] = np.bincount(digit[g * tile:(g + 1) * tile], minlength=16)
+        counts = np.bincount(digit, minlength=16).astype(np.uint32).reshape(1, 16)
         parts = oracle.partition(cfg, counts)
         order = np.argsort(digit, kind="stable")
         dst[:n] = torch.from_numpy(k[order].view(np.int32).copy())

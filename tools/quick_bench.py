@@ -11,6 +11,8 @@ log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
 kb = int(sys.argv[3]) if len(sys.argv) > 3 else 4
 vb = int(sys.argv[4]) if len(sys.argv) > 4 else 0
+tpb = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+fuse = int(sys.argv[6]) if len(sys.argv) > 6 else 1
 n = 1 << log2n
 dev = torch.device("cuda:0")
 kdt = torch.int32 if kb == 4 else torch.int64
@@ -21,7 +23,9 @@ if vb:
     v = torch.empty(n, dtype=torch.int32, device=dev)
     vswap = torch.empty_like(v)
 s = radx_amd.Sorter(n, kb, vb)
+s.tune(bool(fuse))
 s.profile(True)
+print("tiles_per_block", tpb, "fuse", fuse)
 passes = kb * 2
 for it in range(iters):
     if kb == 4:
