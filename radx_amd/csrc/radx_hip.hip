@@ -420,18 +420,18 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         const uint32_t start = (ctr[(tid & 7u) * kBlock] >> ((tid >> 3) << 4)) & 0xffffu;
         where_s[tid] = make_uint2(run_base - start, run_base >> LOG_TILE);
     }
+    if (FUSE) {
+        // The rank counters are dead once read: every thread clears the column only it read
+        // (column 0 is also read by lanes 1..15 of thread 0's own wave, earlier in program order),
+        // so the words can serve as the zeroed next-pass counters after the next barrier.
+#pragma unroll
+        for (int r = 0; r < kCtrRows; ++r) ctr[r * kBlock + tid] = 0u;
+        next_second[tid] = 0u;
+    }
     K* skeys = reinterpret_cast<K*>(stage);
 #pragma unroll
     for (int i = 0; i < KPT; ++i) skeys[rank[i]] = key[i];
     __syncthreads();
-
-    if (FUSE) {
-        // the rank counters are dead: their words become the zeroed next-pass counters
-        *reinterpret_cast<uint4*>(&ctr[tid * 8u]) = make_uint4(0u, 0u, 0u, 0u);
-        *reinterpret_cast<uint4*>(&ctr[tid * 8u + 4u]) = make_uint4(0u, 0u, 0u, 0u);
-        next_second[tid] = 0u;
-        __syncthreads();
-    }
 
     uint32_t dst[HAS_V ? KPT : 1];
     const uint32_t col = tid & 31u;

@@ -20,14 +20,18 @@ src = os.path.join(root, "gpurun_out", "prof_" + tag)
 dst = os.path.join(root, "profiles")
 os.makedirs(dst, exist_ok=True)
 
-stats = glob.glob(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))[0]
+def newest(pattern):
+    return max(glob.glob(pattern), key=os.path.getmtime)
+
+
+stats = newest(os.path.join(src, "stats", "*", "*_kernel_stats.csv"))
 shutil.copy(stats, os.path.join(dst, tag + "_kernel_stats.csv"))
 shutil.copy(os.path.join(src, "bench_under_rocprof.json"), os.path.join(dst, tag + "_bench_under_rocprof.json"))
 
 rows = []
 per = {}
 for counter, sub in (("FETCH_SIZE", "pmc_fetch"), ("WRITE_SIZE", "pmc_write")):
-    f = glob.glob(os.path.join(src, sub, "*", "*_counter_collection.csv"))[0]
+    f = newest(os.path.join(src, sub, "*", "*_counter_collection.csv"))
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         agg[r["Kernel_Name"]].append(float(r["Counter_Value"]))
@@ -42,18 +46,23 @@ with open(os.path.join(dst, tag + "_pmc.csv"), "w", newline="") as f:
         w.writerow([name, counter, cnt, "%.1f" % kb, "%.0f" % (kb * 1024 * (2 if counter == "FETCH_SIZE" else 1))])
 
 
-def corrected(prefix):
+def corrected(*needles):
+    rd = wr = None
     for name, c in per.items():
-        if prefix in name:
-            return 2 * c.get("FETCH_SIZE", 0) * 1024, c.get("WRITE_SIZE", 0) * 1024
-    return None, None
+        if all(x in name for x in needles):
+            rd = 2 * c.get("FETCH_SIZE", 0) * 1024
+            wr = c.get("WRITE_SIZE", 0) * 1024
+    return rd, wr
 
 
 out = {"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
        "`python3 bench.py --steps 1 --warmup 0 --no-cpu`, 2^30 uint32 keys",
        "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); WRITE_SIZE exact"}
-for key, prefix in (("scatter", "scatter_kernel"), ("hist", "hist_kernel")):
-    rd, wr = corrected(prefix)
+# scatter_kernel<K, HAS_V, FUSE>: the fused variant (7 of 8 passes) also counts the next pass's digits
+for key, needles in (("scatter", ("scatter_kernel<unsigned int, false, true>",)),
+                     ("scatter_last_pass", ("scatter_kernel<unsigned int, false, false>",)),
+                     ("hist", ("hist_kernel",))):
+    rd, wr = corrected(*needles)
     if rd is not None:
         out[key + "_read_bytes_per_launch"] = rd
         out[key + "_write_bytes_per_launch"] = wr
