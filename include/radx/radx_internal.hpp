@@ -140,9 +140,14 @@ namespace radx {
     };
 
     // reference: radx_internal.hpp:137-148, radx_implement.inl:391-490
+    // reference: shaders-sdk/radix/includes.glsl:137 (declared, never read by the shaders)
+    struct RadicePropStruct { uint32_t Descending = 0, IsSigned = 0; };
+
     class Radix : public Algorithm {
     protected:
         int keyBytes = 4, valueBytes = 0;
+        RadicePropStruct radiceProp{};
+        bool floatKeys = false;
 
         // reference: radx_implement.inl:421-447 — the pass loop, one C-ABI call here
         Result command(const CommandBuffer& cmdBuf, const std::unique_ptr<InternalInterface>& internalInterface,
@@ -164,6 +169,8 @@ namespace radx {
                                     const std::size_t& maxElementCount = 1024 * 1024) override {
             internalInterface->setMaxElementCount(maxElementCount);
             internalInterface->buildMemory(keyBytes, valueBytes).buildDescriptorSet();
+            check_abi(radx_hip_set_key_order(internalInterface->handle(), floatKeys ? 2 : (radiceProp.IsSigned ? 1 : 0),
+                                             radiceProp.Descending ? 1 : 0));
             return SUCCESS;
         }
 
@@ -176,6 +183,10 @@ namespace radx {
         // Sort::initialize.
         Radix& setKeyBytes(int bytes) { keyBytes = bytes; return *this; }
         Radix& setValueBytes(int bytes) { valueBytes = bytes; return *this; }
+        // Key order: descending and/or signed integers (RadicePropStruct), or IEEE floats of the key
+        // width.  Ties keep input order in every case.  Set before Sort::initialize.
+        Radix& setRadiceProp(const RadicePropStruct& prop) { radiceProp = prop; return *this; }
+        Radix& setFloatKeys(bool on) { floatKeys = on; return *this; }
 
         // reference: radx_implement.inl:391-418 builds five pipelines; the kernels here are
         // already part of the loaded code object.

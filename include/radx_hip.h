@@ -105,6 +105,18 @@ int radx_hip_pass_fused(radx_hip_sorter* s, const void* keys_in, void* keys_out,
                         int next_num_bits, int use_fused_counts, void* stream);
 
 /*
+ * Key order of radx_hip_sort / radx_hip_sort_bits on this sorter (default: unsigned ascending).
+ * key_kind 0: unsigned integer keys; 1: two's-complement signed integers; 2: IEEE-754 floats
+ * (binary32 for 4-byte keys, binary64 for 8-byte keys) in the total order -NaN < -inf < ... <
+ * -0 < +0 < ... < +inf < +NaN.  descending != 0 reverses the order; ties still keep input order.
+ * These are the options the reference declares as RadicePropStruct{Descending, IsSigned}
+ * (shaders-sdk/radix/includes.glsl:137) and never reads.  The mapping is applied as the first
+ * pass loads the keys and undone as the last pass stores them: same passes, same traffic.
+ * radx_hip_pass / radx_hip_pass_fused always work on the raw unsigned bits.
+ */
+int radx_hip_set_key_order(radx_hip_sorter* s, int key_kind, int descending);
+
+/*
  * Tuning knob.  fuse_histogram (default 1): let every scatter pass of radx_hip_sort produce the
  * next pass's histogram; 0 runs the histogram kernel every pass.  The sorted result and the
  * tables do not depend on it.

@@ -29,6 +29,7 @@ SIGNATURES = {
     "radx_hip_pass_fused": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,
                                            ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, _vp]),
     "radx_hip_tune": (ctypes.c_int, [_vp, ctypes.c_int]),
+    "radx_hip_set_key_order": (ctypes.c_int, [_vp, ctypes.c_int, ctypes.c_int]),
     "radx_hip_geometry": (ctypes.c_int, [_vp, ctypes.c_uint64, _u32p, _u32p]),
     "radx_hip_copy_tables": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, _vp, _vp]),
     "radx_hip_digit_starts": (ctypes.c_int, [_vp, _u32p, _vp]),

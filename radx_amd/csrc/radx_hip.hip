@@ -71,6 +71,34 @@ __device__ __forceinline__ uint32_t digit_of(K key, int bit, uint32_t mask) {
     return static_cast<uint32_t>(key >> bit) & mask;
 }
 
+// Key orders other than "unsigned ascending" (the reference declares them as
+// RadicePropStruct{Descending, IsSigned}, shaders-sdk/radix/includes.glsl:137, and never reads
+// them).  The kernels only ever sort unsigned ascending; a sort in another order maps every key
+// to the unsigned integer with the same rank as it is loaded by the first pass and maps it back
+// as the last pass stores it, so no extra traffic.  mode bits: 1 two's-complement signed,
+// 2 IEEE float (total order by sign and magnitude: -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN),
+// 4 descending.
+constexpr int kOrderSigned = 1, kOrderFloat = 2, kOrderDescending = 4;
+
+template <typename K>
+__host__ __device__ __forceinline__ K key_to_ordered(K k, int mode) {
+    constexpr int TOP = sizeof(K) * 8 - 1;
+    constexpr K SIGN = static_cast<K>(1) << TOP;
+    if (mode & kOrderFloat) k ^= ((k >> TOP) ? static_cast<K>(~static_cast<K>(0)) : SIGN);
+    else if (mode & kOrderSigned) k ^= SIGN;
+    if (mode & kOrderDescending) k = static_cast<K>(~k);
+    return k;
+}
+template <typename K>
+__host__ __device__ __forceinline__ K ordered_to_key(K k, int mode) {
+    constexpr int TOP = sizeof(K) * 8 - 1;
+    constexpr K SIGN = static_cast<K>(1) << TOP;
+    if (mode & kOrderDescending) k = static_cast<K>(~k);
+    if (mode & kOrderFloat) k ^= ((k >> TOP) ? SIGN : static_cast<K>(~static_cast<K>(0)));
+    else if (mode & kOrderSigned) k ^= SIGN;
+    return k;
+}
+
 // The 32-bit integer hash the reference harness carries for key generation
 // (src/test/sort.cpp:226-234): six add/xor-shift rounds.
 __host__ __device__ __forceinline__ uint32_t harness_hash(uint32_t a) {
@@ -122,7 +150,7 @@ __device__ __forceinline__ uint32_t tile_image_dword(uint32_t row, uint32_t c) {
 template <typename K>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys, uint32_t n, int bit,
                                                        uint32_t mask, uint32_t* __restrict__ counts,
-                                                       uint32_t num_tiles) {
+                                                       uint32_t num_tiles, int order_in) {
     constexpr int KPT = KeyTraits<K>::kpt;
     constexpr uint32_t TILE = kBlock * KPT;
     constexpr int PER_VEC = 16 / sizeof(K);
@@ -148,14 +176,14 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
             unpack4<K>(v[m], k);
 #pragma unroll
             for (int j = 0; j < PER_VEC; ++j) {
-                const uint32_t d = digit_of<K>(k[j], bit, mask);
+                const uint32_t d = digit_of<K>(key_to_ordered<K>(k[j], order_in), bit, mask);
                 __hip_atomic_fetch_add(&bins[d * 32u + col], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
     } else {
         for (uint32_t i = tid; i < valid; i += kBlock) {
-            const uint32_t d = digit_of<K>(keys[base + i], bit, mask);
+            const uint32_t d = digit_of<K>(key_to_ordered<K>(keys[base + i], order_in), bit, mask);
             __hip_atomic_fetch_add(&bins[d * 32u + col], 1u, __ATOMIC_RELAXED,
                                    __HIP_MEMORY_SCOPE_WORKGROUP);
         }
@@ -300,7 +328,8 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* __restrict__ vin,
     uint32_t* __restrict__ vout, uint32_t n, int bit, uint32_t mask,
     const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ group_sums,
-    uint32_t num_tiles, int next_bit, uint32_t next_mask, uint32_t* __restrict__ next_counts) {
+    uint32_t num_tiles, int next_bit, uint32_t next_mask, uint32_t* __restrict__ next_counts,
+    int order_in, int order_out) {
     constexpr int KPT = KeyTraits<K>::kpt;
     constexpr int LOG_TILE = KeyTraits<K>::log_tile;
     constexpr uint32_t TILE = kBlock * KPT;
@@ -350,7 +379,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         // keys past the end (they take the highest ranks of the last digit and are not stored)
 #pragma unroll 1
         for (uint32_t e = tid; e < TILE; e += kBlock) {
-            const K k = e < valid ? kin[base + e] : static_cast<K>(~static_cast<K>(0));
+            const K k = e < valid ? kin[base + e] : ordered_to_key<K>(static_cast<K>(~static_cast<K>(0)), order_in);
             const uint32_t at = tile_image_dword(e / KPT, (e % KPT) * KEY_DWORDS);
             stage[at] = static_cast<uint32_t>(k);
             if (KEY_DWORDS == 2) stage[at + 1] = static_cast<uint32_t>(static_cast<uint64_t>(k) >> 32);
@@ -365,6 +394,10 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     for (int m = 0; m < NVEC; ++m) {
         const uint4 q = *reinterpret_cast<const uint4*>(&stage[tile_image_dword(tid, 4u * m)]);
         unpack4<K>(q, &key[m * PER_VEC]);
+    }
+    if (order_in) {  // first pass of a sort in a non-default key order
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) key[i] = key_to_ordered<K>(key[i], order_in);
     }
 
     // 2. thread-private packed counters.
@@ -444,7 +477,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         const uint32_t where = w.x + s;
         if (HAS_V) dst[m] = where;
         if (s < valid) {
-            kout[where] = k;
+            kout[where] = order_out ? ordered_to_key<K>(k, order_out) : k;  // last pass restores the key's own bits
             if (FUSE) {
                 const uint32_t d2 = digit_of<K>(k, next_bit, next_mask);
                 const uint32_t slot = (d << 4) | d2;
@@ -644,6 +677,7 @@ struct radx_hip_sorter {
     int key_bytes = 4;
     int value_bytes = 0;
     bool fuse = true;
+    int key_order = 0;      // kOrderSigned | kOrderFloat | kOrderDescending
     char* scratch = nullptr;
     ScratchLayout layout{};
     uint32_t* counts[2] = {nullptr, nullptr};
@@ -692,6 +726,7 @@ struct PassArgs {
     bool have_counts;             // counts[cur ^ 1] already holds this pass's histogram (fused by the previous pass)
     bool fuse_next;               // accumulate the next pass's histogram while scattering
     int next_bit, next_num_bits;  // the next pass's digit
+    int order_in, order_out;      // key-order mapping applied as keys are loaded / stored (first / last pass)
 };
 
 template <typename K, bool HAS_V>
@@ -710,7 +745,7 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
     } else {
         LaunchTimer t(s, 0, stream);
         hipLaunchKernelGGL(hist_kernel<K>, dim3(g.num_tiles), dim3(kBlock), 0, stream, kin, a.n, a.bit,
-                           mask, s->counts[s->cur], g.num_tiles);
+                           mask, s->counts[s->cur], g.num_tiles, a.order_in);
     }
     uint32_t* counts = s->counts[s->cur];
     uint32_t* next_counts = s->counts[s->cur ^ 1];
@@ -727,11 +762,11 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
         if (a.fuse_next)
             hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true>), dim3(g.num_tiles), dim3(kBlock), 0, stream,
                                kin, kout, vin, vout, a.n, a.bit, mask, s->offsets, s->group_sums, g.num_tiles,
-                               a.next_bit, next_mask, next_counts);
+                               a.next_bit, next_mask, next_counts, a.order_in, a.order_out);
         else
             hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false>), dim3(g.num_tiles), dim3(kBlock), 0, stream,
                                kin, kout, vin, vout, a.n, a.bit, mask, s->offsets, s->group_sums, g.num_tiles,
-                               0, 0u, static_cast<uint32_t*>(nullptr));
+                               0, 0u, static_cast<uint32_t*>(nullptr), a.order_in, a.order_out);
     }
     RADX_TRY(hipGetLastError());
     s->chained = a.fuse_next;
@@ -835,6 +870,13 @@ int radx_hip_tune(radx_hip_sorter* s, int fuse_histogram) {
     return 0;
 }
 
+int radx_hip_set_key_order(radx_hip_sorter* s, int key_kind, int descending) {
+    if (!s) return bad_arg("sorter is NULL");
+    if (key_kind < 0 || key_kind > 2) return bad_arg("key_kind must be 0 (unsigned), 1 (signed) or 2 (float)");
+    s->key_order = (key_kind == 1 ? kOrderSigned : key_kind == 2 ? kOrderFloat : 0) | (descending ? kOrderDescending : 0);
+    return 0;
+}
+
 int radx_hip_pass(radx_hip_sorter* s, const void* keys_in, void* keys_out, const void* vals_in,
                   void* vals_out, uint64_t n, int bit, int num_bits, void* stream) {
     return radx_hip_pass_fused(s, keys_in, keys_out, vals_in, vals_out, n, bit, num_bits, -1, 0, 0, stream);
@@ -853,7 +895,7 @@ int radx_hip_pass_fused(radx_hip_sorter* s, const void* keys_in, void* keys_out,
     DeviceGuard guard(s->device);
     RADX_TRY(guard.status());
     PassArgs a{keys_in, keys_out, vals_in, vals_out, static_cast<uint32_t>(n), bit, num_bits,
-               use_fused_counts != 0, fuse_next, fuse_next ? next_bit : 0, fuse_next ? next_num_bits : 0};
+               use_fused_counts != 0, fuse_next, fuse_next ? next_bit : 0, fuse_next ? next_num_bits : 0, 0, 0};
     return run_pass(s, a, static_cast<hipStream_t>(stream));
 }
 
@@ -884,6 +926,8 @@ int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* va
         a.have_counts = s->fuse && p > 0;
         a.fuse_next = s->fuse && p + 1 < passes;
         if (a.fuse_next) digit_at(p + 1, &a.next_bit, &a.next_num_bits);
+        a.order_in = p == 0 ? s->key_order : 0;
+        a.order_out = p == passes - 1 ? s->key_order : 0;
         if (const int rc = run_pass(s, a, static_cast<hipStream_t>(stream))) return rc;
     }
     s->chained = false;

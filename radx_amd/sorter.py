@@ -91,6 +91,11 @@ class Sorter:
                                                 _ptr(vals_out), n, bit, num_bits, next_bit, next_num_bits,
                                                 1 if use_fused_counts else 0, _stream(stream, self.device)))
 
+    def set_key_order(self, kind="unsigned", descending=False):
+        """kind: 'unsigned' | 'signed' | 'float' (IEEE bits of the key width); stable either way."""
+        capi.check(capi.lib.radx_hip_set_key_order(self._h, {"unsigned": 0, "signed": 1, "float": 2}[kind],
+                                                   1 if descending else 0))
+
     def tune(self, fuse_histogram=True):
         capi.check(capi.lib.radx_hip_tune(self._h, 1 if fuse_histogram else 0))
 

@@ -291,3 +291,94 @@ def test_full_size_2_28_properties(device):
     assert radx_amd.check_sorted(k) == 0
     assert radx_amd.checksum(k) == before
     s.close()
+
+
+@pytest.mark.parametrize("world", [2, 4, 8, 16])
+def test_sharded_pipeline_single_process(device, world):
+    """The GPU side of the multi-GPU path without a process group: every 'rank' splits its keys by
+    the top log2(world) bits (HipEngine.split), the segments are exchanged by plain copies in the
+    all-to-all-v pattern, and every shard is sorted on the remaining bits (HipEngine.sort_bits)."""
+    import torch
+    from radx_amd.sharded import HipEngine
+    b = world.bit_length() - 1
+    n_local = 50000 + 17
+    cap = n_local * 2
+    eng = HipEngine(cap, 4, 0)
+    inputs = [make_keys("hash", n_local, 4, seed=300 + r) for r in range(world)]
+    split, starts = [], []
+    for r in range(world):
+        src = to_dev(inputs[r], device)
+        dst = torch.empty_like(src)
+        st = eng.split(src, dst, n_local, 32 - b, b)
+        torch.cuda.synchronize()
+        digit = inputs[r] >> np.uint32(32 - b)
+        assert np.array_equal(to_host(dst), inputs[r][np.argsort(digit, kind="stable")])
+        assert np.array_equal(st[:world], np.concatenate([[0], np.cumsum(np.bincount(digit, minlength=world))[:-1]]))
+        assert st[16] == n_local
+        split.append(dst)
+        starts.append(np.concatenate([st[:world], [n_local]]).astype(np.int64))
+    whole = []
+    for r in range(world):  # rank r receives segment r of every source, in source order
+        parts = [split[s][starts[s][r]:starts[s][r + 1]] for s in range(world)]
+        total = sum(p.numel() for p in parts)
+        keys = torch.zeros(cap, dtype=torch.int32, device=device)
+        keys[:total] = torch.cat(parts)
+        work = torch.empty_like(keys)
+        eng.sort_bits(keys, work, total, 0, 32 - b)
+        torch.cuda.synchronize()
+        shard = to_host(keys)[:total]
+        assert np.all((shard >> np.uint32(32 - b)) == r)
+        whole.append(shard.copy())
+    eng.close()
+    assert np.array_equal(np.concatenate(whole), np.sort(np.concatenate(inputs)))
+
+
+def ordered_image(keys, kind, descending):
+    """numpy restatement of the order-preserving map: unsigned image whose ascending order is the wanted order."""
+    bits = keys.itemsize * 8
+    dt = keys.dtype
+    sign = dt.type(1 << (bits - 1))
+    full = dt.type((1 << bits) - 1)
+    k = keys.copy()
+    if kind == "float":
+        neg = (k >> dt.type(bits - 1)).astype(bool)
+        k = np.where(neg, k ^ full, k ^ sign)
+    elif kind == "signed":
+        k = k ^ sign
+    if descending:
+        k = k ^ full
+    return k.astype(dt)
+
+
+@pytest.mark.parametrize("key_bytes", [4, 8])
+@pytest.mark.parametrize("kind", ["unsigned", "signed", "float"])
+@pytest.mark.parametrize("descending", [False, True])
+def test_key_orders(device, key_bytes, kind, descending):
+    """Descending / signed / float orders (declared, unused RadicePropStruct of the reference):
+    the result is the stable sort of the keys by their order-preserving unsigned image, payload
+    following.  No reference output exists for these orders: pinned to numpy only."""
+    import torch
+    import radx_amd
+    n = 70001
+    keys = make_keys("uniform", n, key_bytes, seed=31)
+    keys[::5] = make_keys("few_distinct", n, key_bytes, seed=32)[::5]      # ties
+    keys[:8] = np.array([0, 1 << (key_bytes * 8 - 1), (1 << (key_bytes * 8)) - 1, 1, 2, 3, 4, 5], dtype=keys.dtype)
+    if kind == "float":  # include +-0, +-inf, NaNs
+        ft = np.float32 if key_bytes == 4 else np.float64
+        special = np.array([0.0, -0.0, np.inf, -np.inf, np.nan, -np.nan, 1.5, -1.5], dtype=ft).view(keys.dtype)
+        keys[8:16] = special
+    vals = np.arange(n, dtype=np.uint32)
+    s = radx_amd.Sorter(n, key_bytes, 4)
+    s.set_key_order(kind, descending)
+    k, v = gpu_sort(device, keys, vals, sorter=s)
+    s.close()
+    order = np.argsort(ordered_image(keys, kind, descending), kind="stable")
+    assert np.array_equal(k, keys[order]) and np.array_equal(v, vals[order])
+    if kind == "signed" and not descending:
+        st = np.int32 if key_bytes == 4 else np.int64
+        assert np.array_equal(k.view(st), np.sort(keys.view(st), kind="stable"))
+    if kind == "float":
+        ft = np.float32 if key_bytes == 4 else np.float64
+        f = k.view(ft)
+        finite = f[np.isfinite(f)]
+        assert np.all(np.diff(finite) <= 0) if descending else np.all(np.diff(finite) >= 0)
