@@ -188,6 +188,24 @@ namespace radx {
         Radix& setRadiceProp(const RadicePropStruct& prop) { radiceProp = prop; return *this; }
         Radix& setFloatKeys(bool on) { floatKeys = on; return *this; }
 
+        // The index path the reference builds as pipelines 3 and 4 and never dispatches
+        // (radx_implement.inl:413-414; shaders-sdk/radix/indiction.comp:18-29, permutation.comp:18-29):
+        //   indiction:   ptrs[i] = i; cache[i] = in[i]      permutation: in[i] = cache[ptrs[i]]
+        // Sort (key, ptrs) pairs with a value_bytes = 4 sorter in between and wide payload rows
+        // move exactly once.  Rows are elemBytes wide.
+        Radix& indiction(const CommandBuffer& cmdBuf, const DescriptorBufferInfo& ptrs, const DescriptorBufferInfo& cache,
+                         const DescriptorBufferInfo& in, std::size_t count, std::size_t elemBytes) {
+            check_abi(radx_hip_indiction(static_cast<uint32_t*>(ptrs.address()), cache.address(), in.address(), count,
+                                         elemBytes, cmdBuf.stream));
+            return *this;
+        }
+        Radix& permutation(const CommandBuffer& cmdBuf, const DescriptorBufferInfo& in, const DescriptorBufferInfo& cache,
+                           const DescriptorBufferInfo& ptrs, std::size_t count, std::size_t elemBytes) {
+            check_abi(radx_hip_permutation(in.address(), cache.address(), static_cast<const uint32_t*>(ptrs.address()),
+                                           count, elemBytes, cmdBuf.stream));
+            return *this;
+        }
+
         // reference: radx_implement.inl:391-418 builds five pipelines; the kernels here are
         // already part of the loaded code object.
         Result initialize(const std::shared_ptr<Device>& device) override { this->device = device; return SUCCESS; }

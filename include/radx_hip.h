@@ -22,6 +22,8 @@
  *       one iteration of the loop at radx_implement.inl:427-444 (counting, partition,
  *       scattering: shaders-sdk/radix/{counting,partition,scattering}.comp) with the
  *       histogram (binding 3) and prefix-sum (binding 4) tables readable afterwards.
+ *   radx_hip_indiction / radx_hip_permutation
+ *       shaders-sdk/radix/indiction.comp:18-29, permutation.comp:18-29 (index + gather path).
  *   radx_hip_generate_* / radx_hip_check_sorted / radx_hip_checksum
  *       device-side counterparts of the harness's key generation and of the result
  *       comparison the harness omits     src/test/sort.cpp:226-234,342-350,452-469.
@@ -155,6 +157,20 @@ int radx_hip_digit_starts(radx_hip_sorter* s, uint32_t out[17], void* stream);
  */
 int radx_hip_profile(radx_hip_sorter* s, int enable);
 int radx_hip_kernel_times(radx_hip_sorter* s, double ms[3], uint64_t launches[3]);
+
+/*
+ * The reference's index path (shaders-sdk/radix/indiction.comp:18-29, permutation.comp:18-29;
+ * pipelines 3 and 4 of Radix::initialize, include/radx/radx_implement.inl:413-414, never
+ * dispatched by Radix::command): sort (key, index) pairs, then move payload rows of any width once.
+ *   indiction:   ptrs[i] = i;  cache[i] = in[i]        (cache and in may both be NULL: index only)
+ *   permutation: in[i] = cache[ptrs[i]]
+ * Rows are elem_bytes wide (a positive multiple of 4); 16-byte multiples on 16-byte aligned
+ * buffers move as 16-byte words.  Enqueued on `stream`.
+ */
+int radx_hip_indiction(uint32_t* ptrs, void* cache, const void* in, uint64_t n, size_t elem_bytes,
+                       void* stream);
+int radx_hip_permutation(void* in, const void* cache, const uint32_t* ptrs, uint64_t n,
+                         size_t elem_bytes, void* stream);
 
 /* ---- harness utilities (device side of src/test/sort.cpp's generation and checking) ---- */
 

@@ -41,6 +41,10 @@ ref.radx_ref_scattering.argtypes = [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_int, cty
 ref.radx_ref_sort.restype = ctypes.c_int
 ref.radx_ref_sort.argtypes = [_cfgp, _vp, _vp, _vp, _vp, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint32,
                               _vp, _vp]
+ref.radx_ref_indiction.restype = None
+ref.radx_ref_indiction.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_size_t]
+ref.radx_ref_permutation.restype = None
+ref.radx_ref_permutation.argtypes = [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_size_t]
 ref.radx_ref_hash.restype = ctypes.c_uint32
 ref.radx_ref_hash.argtypes = [ctypes.c_uint32]
 ref.radx_ref_generate_u32.restype = None
@@ -173,3 +177,19 @@ def stable_sort_kv(keys, vals):
     fn = cpu.radx_cpu_stable_sort_kv_u32 if k.itemsize == 4 else cpu.radx_cpu_stable_sort_kv_u64
     fn(_p(k), _p(v), k.size)
     return k, v
+
+
+def indiction(src):
+    """(ptrs, cache) of indiction.comp on rows src[i]."""
+    n = src.shape[0]
+    ptrs = np.empty(n, dtype=np.uint32)
+    cache = np.empty_like(src)
+    ref.radx_ref_indiction(_p(ptrs), _p(cache), _p(np.ascontiguousarray(src)), n, src.strides[0] if n else 4)
+    return ptrs, cache
+
+
+def permutation(cache, ptrs):
+    out = np.empty_like(cache)
+    ref.radx_ref_permutation(_p(out), _p(np.ascontiguousarray(cache)), _p(np.ascontiguousarray(ptrs)), ptrs.size,
+                             cache.strides[0] if ptrs.size else 4)
+    return out

@@ -203,6 +203,20 @@ int radx_ref_sort(const radx_ref_config* cfg, void* keys, void* swap, uint32_t* 
     return (int)(passes & 1u);
 }
 
+/* shaders-sdk/radix/indiction.comp:18-29 */
+void radx_ref_indiction(uint32_t* ptrs, void* cache, const void* in, uint64_t n, size_t elem_bytes) {
+    for (uint64_t id = 0; id < n; ++id) {
+        ptrs[id] = (uint32_t)id;                                              /* :27 ptrs[0].data[globalID] = globalID */
+        if (cache && in) memcpy((char*)cache + id * elem_bytes, (const char*)in + id * elem_bytes, elem_bytes);
+    }
+}
+
+/* shaders-sdk/radix/permutation.comp:18-29 */
+void radx_ref_permutation(void* in, const void* cache, const uint32_t* ptrs, uint64_t n, size_t elem_bytes) {
+    for (uint64_t id = 0; id < n; ++id)                                       /* :27 keyIn[id] = keyExtra[ptrs[id]] */
+        memcpy((char*)in + id * elem_bytes, (const char*)cache + (uint64_t)ptrs[id] * elem_bytes, elem_bytes);
+}
+
 /* src/test/sort.cpp:226-234 */
 uint32_t radx_ref_hash(uint32_t a) {
     a = (a + 0x7ed55d16u) + (a << 12);

@@ -81,6 +81,11 @@ int radx_ref_sort(const radx_ref_config* cfg, void* keys, void* swap, uint32_t* 
                   uint32_t* vals_swap, int key_bytes, uint32_t n, uint32_t passes,
                   uint32_t* counts_log, uint32_t* partitions_log);
 
+/* indiction — shaders-sdk/radix/indiction.comp:18-29: ptrs[i] = i; cache[i] = in[i] (rows of elem_bytes) */
+void radx_ref_indiction(uint32_t* ptrs, void* cache, const void* in, uint64_t n, size_t elem_bytes);
+/* permutation — shaders-sdk/radix/permutation.comp:18-29: in[i] = cache[ptrs[i]] */
+void radx_ref_permutation(void* in, const void* cache, const uint32_t* ptrs, uint64_t n, size_t elem_bytes);
+
 /* hash — src/test/sort.cpp:226-234 */
 uint32_t radx_ref_hash(uint32_t a);
 

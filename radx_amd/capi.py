@@ -35,6 +35,8 @@ SIGNATURES = {
     "radx_hip_digit_starts": (ctypes.c_int, [_vp, _u32p, _vp]),
     "radx_hip_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
     "radx_hip_kernel_times": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _u64p]),
+    "radx_hip_indiction": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_size_t, _vp]),
+    "radx_hip_permutation": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_size_t, _vp]),
     "radx_hip_generate_u32": (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_uint32, _vp]),
     "radx_hip_generate_u64": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_uint32, _vp]),
     "radx_hip_check_sorted": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_int, _u64p, _vp]),

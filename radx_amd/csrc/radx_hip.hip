@@ -209,13 +209,14 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
 // scan: partitions[g][r] = sum_{r' < r} total[r'] + sum_{g' < g} counts[g'][r], the exclusive scan
 // in (radix, workgroup) order that shaders-sdk/radix/partition.comp:29-68 produces in two phases.
 // Kernel 1: every scan workgroup takes 256 consecutive table rows (one per thread) and scans each
-// of the 16 radix columns across them, leaving the column totals.  Kernel 2 (one workgroup) scans
+// of the 16 radix columns across them, leaving the column totals (and zeroes the same rows of the
+// table the following scatter pass accumulates the next pass's counts in).  Kernel 2 (one workgroup) scans
 // those totals in (radix, scan-workgroup) order.  The scatter kernel adds the two parts.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void scan_rows_kernel(const uint32_t* __restrict__ counts,
                                                             uint32_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ group_sums,
-                                                            uint32_t num_tiles) {
+                                                            uint32_t num_tiles, uint32_t* __restrict__ clear) {
     __shared__ uint32_t wave_tot[kBlock / 64][kRadices];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t row = blockIdx.x * kScanBlocks + tid;
@@ -252,51 +253,70 @@ __global__ __launch_bounds__(kBlock) void scan_rows_kernel(const uint32_t* __res
         uint4* dst = reinterpret_cast<uint4*>(offsets + static_cast<size_t>(row) * kRadices);
 #pragma unroll
         for (int q = 0; q < 4; ++q) dst[q] = make_uint4(o[4 * q], o[4 * q + 1], o[4 * q + 2], o[4 * q + 3]);
+        if (clear) {  // the table the following scatter pass adds the next pass's counts into
+            uint4* z = reinterpret_cast<uint4*>(clear + static_cast<size_t>(row) * kRadices);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) z[q] = make_uint4(0u, 0u, 0u, 0u);
+        }
     }
     if (tid < static_cast<uint32_t>(kRadices)) {
         uint32_t all = 0;
 #pragma unroll
         for (int w = 0; w < kBlock / 64; ++w) all += wave_tot[w][tid];
-        group_sums[static_cast<size_t>(blockIdx.x) * kRadices + tid] = all;
+        group_sums[static_cast<size_t>(tid) * gridDim.x + blockIdx.x] = all;
     }
 }
 
-// group_sums[j][d] -> exclusive scan over the linear order L = d * num_groups + j, in place.
+// group_sums[d][j] (radix-major, so the (radix, scan-workgroup) order is the linear order of the
+// array) -> exclusive scan in place.  One workgroup; per round every thread owns 16 consecutive
+// words, loaded up front (independent loads), summed, block-scanned and rewritten.  One round
+// covers 16 Ki words = 2^30 uint32 keys.
 __global__ __launch_bounds__(1024) void scan_groups_kernel(uint32_t* __restrict__ group_sums,
                                                             uint32_t num_groups, uint32_t n,
                                                             uint32_t* __restrict__ digit_starts) {
+    constexpr int PER = 16;
     __shared__ uint32_t wave_tot[16];
-    __shared__ uint32_t carry_s;
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t len = num_groups * kRadices;
-    if (tid == 0u) carry_s = 0u;
-    __syncthreads();
-    for (uint32_t start = 0; start < len; start += 1024u) {
-        const uint32_t L = start + tid;
-        const uint32_t d = L / num_groups, j = L - d * num_groups;
-        const size_t at = static_cast<size_t>(j) * kRadices + d;
-        const uint32_t v = L < len ? group_sums[at] : 0u;
-        const uint32_t incl = wave_inclusive_scan(v);
+    uint32_t carry = 0;
+    for (uint32_t round = 0; round < len; round += 1024u * PER) {
+        const uint32_t first = round + tid * PER;
+        uint32_t v[PER];
+        if (first + PER <= len) {
+#pragma unroll
+            for (int q = 0; q < PER / 4; ++q) {
+                const uint4 a = *reinterpret_cast<const uint4*>(group_sums + first + 4 * q);
+                v[4 * q] = a.x; v[4 * q + 1] = a.y; v[4 * q + 2] = a.z; v[4 * q + 3] = a.w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < PER; ++i) v[i] = first + i < len ? group_sums[first + i] : 0u;
+        }
+        uint32_t total = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) total += v[i];
+        const uint32_t incl = wave_inclusive_scan(total);
+        __syncthreads();  // wave_tot of the previous round has been read by everyone
         if (lane == 63u) wave_tot[wave] = incl;
         __syncthreads();
-        uint32_t before = 0, all = 0;
+        uint32_t run = carry + incl - total, all = 0;
 #pragma unroll
         for (int w = 0; w < 16; ++w) {
             const uint32_t t = wave_tot[w];
-            if (static_cast<uint32_t>(w) < wave) before += t;
+            if (static_cast<uint32_t>(w) < wave) run += t;
             all += t;
         }
-        const uint32_t carry = carry_s;
-        const uint32_t excl = carry + before + incl - v;
-        // Reads of this round happened before the barrier above and every word is read and
-        // written by the same thread, so the in-place update is safe.
-        if (L < len) {
-            group_sums[at] = excl;
-            if (j == 0u) digit_starts[d] = excl;  // start of every digit's output run
+        carry += all;
+        // every word is read and rewritten by the same thread only, so in place is safe
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t L = first + i;
+            if (L < len) {
+                group_sums[L] = run;
+                if (L % num_groups == 0u) digit_starts[L / num_groups] = run;  // start of every digit's output run
+                run += v[i];
+            }
         }
-        __syncthreads();
-        if (tid == 0u) carry_s = carry + all;
-        __syncthreads();
     }
     if (tid == 0u) digit_starts[kRadices] = n;
 }
@@ -352,7 +372,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     uint32_t run_base = 0;
     if (tid < static_cast<uint32_t>(kRadices))
         run_base = offsets[static_cast<size_t>(g) * kRadices + tid] +
-                   group_sums[static_cast<size_t>(g / kScanBlocks) * kRadices + tid];
+                   group_sums[static_cast<size_t>(tid) * ((num_tiles + kScanBlocks - 1) / kScanBlocks) + g / kScanBlocks];
 
     K key[KPT];
     uint32_t val[HAS_V ? KPT : 1];
@@ -523,6 +543,40 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
             const uint32_t s = m * kBlock + tid;
             if (s < valid) vout[dst[m]] = stage[s];
         }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// index path: the reference's indiction / permutation kernels (shaders-sdk/radix/indiction.comp:18-29,
+// permutation.comp:18-29; built by Radix::initialize, never dispatched by Radix::command).  They
+// exist so that wide payloads need not ride through every pass: sort (key, index) pairs, then
+// gather the payload rows once through the sorted index.  Rows are elem_words units of T
+// (T = 16-byte or 4-byte words); consecutive lanes copy consecutive words, so writes are
+// coalesced and each row is read as one contiguous burst.
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(kBlock) void indiction_kernel(uint32_t* __restrict__ ptrs, T* __restrict__ cache,
+                                                            const T* __restrict__ in, uint64_t n,
+                                                            uint32_t elem_words) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const uint64_t first = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    for (uint64_t i = first; i < n; i += stride) ptrs[i] = static_cast<uint32_t>(i);     // ptrs[id] = id
+    if (cache) {
+        const uint64_t words = n * elem_words;
+        for (uint64_t f = first; f < words; f += stride) cache[f] = in[f];               // keyExtra[id] = keyIn[id]
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void permutation_kernel(T* __restrict__ in, const T* __restrict__ cache,
+                                                              const uint32_t* __restrict__ ptrs, uint64_t n,
+                                                              uint32_t elem_words, int log2_words) {
+    const uint64_t stride = static_cast<uint64_t>(gridDim.x) * blockDim.x;
+    const uint64_t words = n * elem_words;
+    for (uint64_t f = static_cast<uint64_t>(blockIdx.x) * blockDim.x + threadIdx.x; f < words; f += stride) {
+        const uint64_t i = log2_words >= 0 ? f >> log2_words : f / elem_words;
+        const uint64_t w = f - i * elem_words;
+        in[f] = cache[static_cast<uint64_t>(ptrs[i]) * elem_words + w];                   // keyIn[id] = keyExtra[ptrs[id]]
     }
 }
 
@@ -734,7 +788,6 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
     const Geometry g = geometry_for(a.n, sizeof(K));
     const uint32_t mask = (1u << a.num_bits) - 1u;
     const uint32_t next_mask = (1u << a.next_num_bits) - 1u;
-    const size_t table_bytes = static_cast<size_t>(g.num_tiles) * kRadices * 4;
     const K* kin = static_cast<const K*>(a.kin);
     K* kout = static_cast<K*>(a.kout);
     const uint32_t* vin = static_cast<const uint32_t*>(a.vin);
@@ -751,9 +804,8 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
     uint32_t* next_counts = s->counts[s->cur ^ 1];
     {
         LaunchTimer t(s, 1, stream);
-        if (a.fuse_next) RADX_TRY(hipMemsetAsync(next_counts, 0, table_bytes, stream));
         hipLaunchKernelGGL(scan_rows_kernel, dim3(g.num_groups), dim3(kBlock), 0, stream, counts, s->offsets,
-                           s->group_sums, g.num_tiles);
+                           s->group_sums, g.num_tiles, a.fuse_next ? next_counts : static_cast<uint32_t*>(nullptr));
         hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, stream, s->group_sums, g.num_groups,
                            a.n, s->digit_starts);
     }
@@ -964,7 +1016,7 @@ int radx_hip_copy_tables(radx_hip_sorter* s, uint64_t n, uint32_t* counts, uint3
         RADX_TRY(hipMemcpy(offsets, s->offsets, words * 4, hipMemcpyDeviceToHost));
         RADX_TRY(hipMemcpy(sums.data(), s->group_sums, sums.size() * 4, hipMemcpyDeviceToHost));
         for (size_t i = 0; i < words; ++i)
-            offsets[i] += sums[(i / kRadices / kScanBlocks) * kRadices + (i % kRadices)];
+            offsets[i] += sums[(i % kRadices) * g.num_groups + i / kRadices / kScanBlocks];
     }
     return 0;
 }
@@ -1003,6 +1055,55 @@ int radx_hip_kernel_times(radx_hip_sorter* s, double ms[3], uint64_t launches[3]
         s->ms[i] = 0;
         s->launches[i] = 0;
     }
+    return 0;
+}
+
+namespace {
+int log2_or_minus1(uint32_t v) {
+    if (v == 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1u << l) < v) ++l;
+    return l;
+}
+}  // namespace
+
+int radx_hip_indiction(uint32_t* ptrs, void* cache, const void* in, uint64_t n, size_t elem_bytes, void* stream) {
+    if (n == 0) return 0;
+    if (!ptrs) return bad_arg("ptrs is NULL");
+    if (n > kMaxElements) return bad_arg("n must be < 2^32");
+    if ((cache == nullptr) != (in == nullptr)) return bad_arg("cache and in go together");
+    if (cache && (elem_bytes == 0 || elem_bytes % 4)) return bad_arg("elem_bytes must be a positive multiple of 4");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool wide = cache && elem_bytes % 16 == 0 && aligned16(cache) && aligned16(in);
+    if (wide)
+        hipLaunchKernelGGL(indiction_kernel<uint4>, dim3(8192), dim3(kBlock), 0, st, ptrs, static_cast<uint4*>(cache),
+                           static_cast<const uint4*>(in), n, static_cast<uint32_t>(elem_bytes / 16));
+    else
+        hipLaunchKernelGGL(indiction_kernel<uint32_t>, dim3(8192), dim3(kBlock), 0, st, ptrs,
+                           static_cast<uint32_t*>(cache), static_cast<const uint32_t*>(in), n,
+                           static_cast<uint32_t>(elem_bytes / 4));
+    RADX_TRY(hipGetLastError());
+    return 0;
+}
+
+int radx_hip_permutation(void* in, const void* cache, const uint32_t* ptrs, uint64_t n, size_t elem_bytes,
+                         void* stream) {
+    if (n == 0) return 0;
+    if (!in || !cache || !ptrs) return bad_arg("NULL buffer");
+    if (in == cache) return bad_arg("in and cache are the same buffer");
+    if (n > kMaxElements) return bad_arg("n must be < 2^32");
+    if (elem_bytes == 0 || elem_bytes % 4) return bad_arg("elem_bytes must be a positive multiple of 4");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (elem_bytes % 16 == 0 && aligned16(in) && aligned16(cache)) {
+        const uint32_t words = static_cast<uint32_t>(elem_bytes / 16);
+        hipLaunchKernelGGL(permutation_kernel<uint4>, dim3(8192), dim3(kBlock), 0, st, static_cast<uint4*>(in),
+                           static_cast<const uint4*>(cache), ptrs, n, words, log2_or_minus1(words));
+    } else {
+        const uint32_t words = static_cast<uint32_t>(elem_bytes / 4);
+        hipLaunchKernelGGL(permutation_kernel<uint32_t>, dim3(8192), dim3(kBlock), 0, st, static_cast<uint32_t*>(in),
+                           static_cast<const uint32_t*>(cache), ptrs, n, words, log2_or_minus1(words));
+    }
+    RADX_TRY(hipGetLastError());
     return 0;
 }
 

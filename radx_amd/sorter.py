@@ -159,3 +159,17 @@ def checksum(keys, n=None, stream=None):
     capi.check(capi.lib.radx_hip_checksum(_ptr(keys), n, keys.element_size(), out,
                                           _stream(stream, keys.device)))
     return tuple(int(v) for v in out)
+
+
+def indiction(ptrs, cache=None, src=None, n=None, stream=None):
+    """ptrs[i] = i and, when given, cache[i] = src[i] (rows = src.shape[1:])."""
+    n = ptrs.numel() if n is None else int(n)
+    row = 4 if src is None else src[0].numel() * src.element_size() if src.dim() > 1 else src.element_size()
+    capi.check(capi.lib.radx_hip_indiction(_ptr(ptrs), _ptr(cache), _ptr(src), n, row, _stream(stream, ptrs.device)))
+
+
+def permutation(dst, cache, ptrs, n=None, stream=None):
+    """dst[i] = cache[ptrs[i]] (rows = dst.shape[1:])."""
+    n = ptrs.numel() if n is None else int(n)
+    row = dst[0].numel() * dst.element_size() if dst.dim() > 1 else dst.element_size()
+    capi.check(capi.lib.radx_hip_permutation(_ptr(dst), _ptr(cache), _ptr(ptrs), n, row, _stream(stream, dst.device)))

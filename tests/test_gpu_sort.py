@@ -382,3 +382,34 @@ def test_key_orders(device, key_bytes, kind, descending):
         f = k.view(ft)
         finite = f[np.isfinite(f)]
         assert np.all(np.diff(finite) <= 0) if descending else np.all(np.diff(finite) >= 0)
+
+
+@pytest.mark.parametrize("row_words", [1, 3, 4, 12, 16])
+def test_index_path_sort_then_gather(device, row_words):
+    """indiction -> (key, index) sort -> permutation: wide payload rows moved once, against the
+    oracle's restatement of indiction.comp / permutation.comp and a numpy stable argsort."""
+    import torch
+    import radx_amd
+    rng = np.random.default_rng(row_words)
+    n = 30000 + row_words
+    keys = make_keys("few_distinct", n, 4, seed=4)
+    keys[::2] = make_keys("uniform", n, 4, seed=5)[::2]
+    rows = rng.integers(0, 1 << 32, size=(n, row_words), dtype=np.uint32)
+    d_rows = torch.from_numpy(rows.view(np.int32)).to(device)
+    d_cache = torch.empty_like(d_rows)
+    d_ptrs = torch.empty(n, dtype=torch.int32, device=device)
+    radx_amd.indiction(d_ptrs, d_cache, d_rows)
+    torch.cuda.synchronize()
+    ptrs, cache = oracle.indiction(rows)
+    assert np.array_equal(to_host(d_ptrs), ptrs) and np.array_equal(d_cache.cpu().numpy().view(np.uint32), cache)
+    s = radx_amd.Sorter(n, 4, 4)
+    dk = to_dev(keys, device)
+    s.sort(dk, torch.empty_like(dk), d_ptrs, torch.empty_like(d_ptrs))
+    radx_amd.permutation(d_rows, d_cache, d_ptrs)
+    torch.cuda.synchronize()
+    s.close()
+    hk, hidx = oracle.sort(oracle.engine_config(n, 4), keys, ptrs)
+    assert np.array_equal(to_host(dk), hk) and np.array_equal(to_host(d_ptrs), hidx)
+    want = oracle.permutation(cache, hidx)
+    assert np.array_equal(d_rows.cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(want, rows[np.argsort(keys, kind="stable")])

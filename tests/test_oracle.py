@@ -121,3 +121,17 @@ def test_parallel_sort_and_checksums():
     assert oracle.checksum(keys)[0] == int(keys.astype(np.uint64).sum())
     assert oracle.cpu.radx_cpu_threads() >= 1
     assert oracle.cpu.radx_cpu_pstl_backend() in (b"tbb", b"serial")
+
+
+def test_index_path_indiction_permutation():
+    # indiction.comp:27 / permutation.comp:27: sort (key, index), then gather rows through the index
+    rng = np.random.default_rng(3)
+    n = 5000
+    keys = make_keys("few_distinct", n, 4, seed=2)
+    rows = rng.integers(0, 1 << 32, size=(n, 5), dtype=np.uint32)
+    ptrs, cache = oracle.indiction(rows)
+    assert np.array_equal(ptrs, np.arange(n, dtype=np.uint32)) and np.array_equal(cache, rows)
+    k, idx = oracle.sort(oracle.engine_config(n, 4), keys, ptrs)
+    out = oracle.permutation(cache, idx)
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(k, keys[order]) and np.array_equal(out, rows[order])

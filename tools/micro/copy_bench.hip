@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>
+#include <stdlib.h>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
 
 __device__ __forceinline__ uint32_t remap(uint32_t bid, uint32_t nwg) {
@@ -82,8 +83,8 @@ template <bool NT_ST> __global__ __launch_bounds__(256) void copy_runs_nt(const 
         if (NT_ST) __builtin_nontemporal_store(l[m * 256 + threadIdx.x], &out[where]); else out[where] = l[m * 256 + threadIdx.x];
     }
 }
-int main() {
-    const size_t n = (size_t)1 << 30; const uint32_t tiles = n / 4096;
+int main(int argc, char** argv) {
+    const size_t n = (size_t)1 << (argc > 1 ? atoi(argv[1]) : 30); const uint32_t tiles = n / 4096;
     uint32_t *a, *b; CK(hipMalloc(&a, n * 4)); CK(hipMalloc(&b, n * 4));
     CK(hipMemset(a, 1, n * 4)); CK(hipMemset(b, 2, n * 4));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
