@@ -7,7 +7,10 @@
 // leaves out: seeded inputs and a bit-exact comparison of the two results.
 //
 //   sort_test [--n N | --log2n L] [--type u32|u64kv] [--dist uniform|shuffle|hash] [--seed S]
-//             [--iters I] [--device D] [--cpu-only]
+//             [--iters I] [--device D] [--batches B] [--cpu-only]
+//
+// --batches B sorts B independent host-resident arrays through pinned staging buffers with upload,
+// sort and download overlapped on three streams, and reports the PCIe-inclusive rate.
 //
 // --cpu-only runs the plumbing without touching a GPU: generation, the reference's CPU
 // comparator std::stable_sort(std::execution::par, ...) (src/test/sort.cpp:218-219) and the
@@ -35,7 +38,7 @@ struct Options {
     size_t n = size_t(1) << 23;  // the reference's hard-coded size (src/test/sort.hpp:184)
     std::string type = "u32", dist = "shuffle";
     uint64_t seed = 1;
-    int iters = 3, device = 0;
+    int iters = 3, device = 0, batches = 0;
     bool cpuOnly = false;
 };
 
@@ -192,6 +195,92 @@ public:
         return pass ? 0 : 1;
     }
 
+    // Staging for callers whose data starts and ends on the host (the upload / download command
+    // buffers around the sort, src/test/sort.cpp:396-401,418-423): `batches` independent arrays in
+    // pinned host memory, two device slots, three streams.  Batch i+1 uploads and batch i-1
+    // downloads while batch i sorts; the reported rate includes PCIe both ways.
+    int runStaged(const Options& o) {
+        const size_t n = o.n;
+        const int B = o.batches;
+        physicalHelper = std::make_shared<radx::PhysicalDeviceHelper>(radx::PhysicalDevice(o.device));
+        device = std::make_shared<radx::Device>()->initialize(radx::LogicalDevice(o.device), physicalHelper);
+        program = std::make_shared<radx::Radix>(); program->initialize(device);
+        radixSort = std::make_shared<radx::Sort<radx::Radix>>(); radixSort->initialize(device, program, n);
+
+        const size_t keysSize = (n * sizeof(uint32_t) + 15) & ~size_t(15);
+        std::shared_ptr<radx::VmaAllocatedBuffer> slotBuffer[2];
+        std::shared_ptr<radx::InputInterface> slotInput[2];
+        radx::Vector<uint32_t> slotKeys[2];
+        for (int s = 0; s < 2; ++s) {
+            slotBuffer[s] = std::make_shared<radx::VmaAllocatedBuffer>(device, 2 * keysSize, 0, radx::MEMORY_USAGE_GPU_ONLY);
+            slotKeys[s] = radx::Vector<uint32_t>(slotBuffer[s], n, 0);
+            radx::Vector<uint32_t> swap(slotBuffer[s], n, keysSize);
+            slotInput[s] = std::make_shared<radx::InputInterface>(device);
+            slotInput[s]->setElementCount(n).setKeysBufferInfo(slotKeys[s]).setSwapBufferInfo(swap).buildDescriptorSet();
+        }
+        auto hostIn = std::make_shared<radx::VmaAllocatedBuffer>(device, size_t(B) * keysSize, 0, radx::MEMORY_USAGE_CPU_TO_GPU);
+        auto hostOut = std::make_shared<radx::VmaAllocatedBuffer>(device, size_t(B) * keysSize, 0, radx::MEMORY_USAGE_GPU_TO_CPU);
+        std::vector<radx::Vector<uint32_t>> in, out;
+        for (int b = 0; b < B; ++b) {
+            in.emplace_back(hostIn, n, size_t(b) * keysSize);
+            out.emplace_back(hostOut, n, size_t(b) * keysSize);
+            Options ob = o; ob.seed = o.seed + b;
+            generate(in[b].map(), n, ob);
+        }
+
+        hipStream_t up, run, down;
+        radx::check_hip(hipStreamCreate(&up), "hipStreamCreate");
+        radx::check_hip(hipStreamCreate(&run), "hipStreamCreate");
+        radx::check_hip(hipStreamCreate(&down), "hipStreamCreate");
+        hipEvent_t uploaded[2], sorted[2], downloaded[2];
+        for (int s = 0; s < 2; ++s) {
+            radx::check_hip(hipEventCreateWithFlags(&uploaded[s], hipEventDisableTiming), "hipEventCreate");
+            radx::check_hip(hipEventCreateWithFlags(&sorted[s], hipEventDisableTiming), "hipEventCreate");
+            radx::check_hip(hipEventCreateWithFlags(&downloaded[s], hipEventDisableTiming), "hipEventCreate");
+        }
+        auto pipeline = [&](bool overlap) {
+            const auto t0 = std::chrono::steady_clock::now();
+            for (int b = 0; b < B; ++b) {
+                const int s = b & 1;
+                if (b >= 2) radx::check_hip(hipStreamWaitEvent(up, downloaded[s], 0), "slot free");
+                radx::check_hip(hipMemcpyAsync(slotKeys[s].deviceData(), in[b].data(), n * sizeof(uint32_t),
+                                               hipMemcpyHostToDevice, up), "upload");
+                radx::check_hip(hipEventRecord(uploaded[s], up), "record");
+                radx::check_hip(hipStreamWaitEvent(run, uploaded[s], 0), "wait upload");
+                radixSort->command(radx::CommandBuffer(run), slotInput[s]);
+                radx::check_hip(hipEventRecord(sorted[s], run), "record");
+                radx::check_hip(hipStreamWaitEvent(down, sorted[s], 0), "wait sort");
+                radx::check_hip(hipMemcpyAsync(out[b].data(), slotKeys[s].deviceData(), n * sizeof(uint32_t),
+                                               hipMemcpyDeviceToHost, down), "download");
+                radx::check_hip(hipEventRecord(downloaded[s], down), "record");
+                if (!overlap) radx::check_hip(hipStreamSynchronize(down), "serialise");
+            }
+            radx::check_hip(hipStreamSynchronize(down), "drain");
+            return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        };
+        pipeline(true);  // warm-up (first touch of the pinned pages, code object load)
+        const double serialMs = pipeline(false);
+        const double overlapMs = pipeline(true);
+
+        bool pass = true;
+        std::vector<uint32_t> ref;
+        for (int b = 0; b < B && pass; ++b) {
+            ref.assign(in[b].begin(), in[b].end());
+            parallelSortCPU(ref.data(), ref.data() + ref.size());
+            pass = std::equal(ref.begin(), ref.end(), out[b].begin());
+        }
+        std::cout << "Staged sort of " << B << " batches: " << overlapMs << "ms overlapped, " << serialMs << "ms serialised" << std::endl;
+        std::cout << "Sorting Finished: " << (pass ? "PASS" : "FAIL") << std::endl;
+        const double keys = double(n) * B;
+        std::printf("{\"harness\":\"staged\",\"type\":\"u32\",\"n\":%zu,\"batches\":%d,\"overlapped_ms\":%.3f,\"serialised_ms\":%.3f,"
+                    "\"gkeys_per_s_incl_pcie\":%.3f,\"gkeys_per_s_serialised\":%.3f,\"pcie_GBps_each_way\":%.2f,\"pass\":%s}\n",
+                    n, B, overlapMs, serialMs, keys / overlapMs / 1e6, keys / serialMs / 1e6,
+                    keys * 4 / overlapMs / 1e6, pass ? "true" : "false");
+        for (int s = 0; s < 2; ++s) { (void)hipEventDestroy(uploaded[s]); (void)hipEventDestroy(sorted[s]); (void)hipEventDestroy(downloaded[s]); }
+        (void)hipStreamDestroy(up); (void)hipStreamDestroy(run); (void)hipStreamDestroy(down);
+        return pass ? 0 : 1;
+    }
+
     // uint64 keys + uint32 payload (= original index): the key-value path the reference declares
     // but never wires (shaders-sdk/radix/includes.glsl:128-135,151).
     int runU64KV(const Options& o) {
@@ -270,6 +359,7 @@ int main(int argc, char** argv) {
         else if (a == "--seed") o.seed = std::stoull(next());
         else if (a == "--iters") o.iters = std::max(1, std::stoi(next()));
         else if (a == "--device") o.device = std::stoi(next());
+        else if (a == "--batches") o.batches = std::max(1, std::stoi(next()));
         else if (a == "--cpu-only") o.cpuOnly = true;
         else { std::cerr << "unknown option " << a << "\n"; return 2; }
     }
@@ -278,6 +368,7 @@ int main(int argc, char** argv) {
     try {
         if (o.cpuOnly) return rad::runCpuOnly(o);
         rad::TestSort test;
+        if (o.batches > 0 && o.type == "u32") return test.runStaged(o);
         return o.type == "u32" ? test.runU32(o) : test.runU64KV(o);
     } catch (const std::exception& e) {
         std::cerr << "sort_test: " << e.what() << std::endl;

@@ -32,3 +32,9 @@ def test_harness_u32_sizes(device, n):
 def test_harness_u64_key_value(device, dist):
     line = run("--type", "u64kv", "--log2n", "21", "--dist", dist, "--iters", "1")
     assert line["pass"] is True
+
+
+def test_harness_staged_pipeline(device):
+    line = run("--log2n", "22", "--dist", "uniform", "--batches", "5")
+    assert line["pass"] is True and line["batches"] == 5
+    assert line["overlapped_ms"] > 0 and line["serialised_ms"] > 0
