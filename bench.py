@@ -30,6 +30,7 @@ def parse():
     ap.add_argument("--log2n", type=int, default=30, help="log2 of keys per GPU (30 = README headline size)")
     ap.add_argument("--cpu-log2n", type=int, default=27, help="log2 of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other single-GPU configs")
     return ap.parse_args()
 
 
@@ -62,6 +63,45 @@ def cpu_baseline(log2n):
                     % (min(log2n, 25), oracle.cpu.radx_cpu_pstl_backend().decode()),
             "value": round(m / stable_dt / 1e9, 4), "unit": "Gkeys/s"},
     }
+
+
+def other_configs(dev):
+    """The other single-GPU BASELINE.json configs, timed the same way (every step its own
+    pre-generated batch, wall clock between synchronisations).  Reported beside the headline
+    line, never as `value`."""
+    import torch
+    import radx_amd
+    res = {}
+    for name, log2n, kb, vb, steps in (("2^28 uint32 keys", 28, 4, 0, 10),
+                                       ("2^30 uint64 keys + uint32 payload", 30, 8, 4, 3)):
+        n = 1 << log2n
+        kdt = torch.int32 if kb == 4 else torch.int64
+        keys = [torch.empty(n, dtype=kdt, device=dev) for _ in range(steps + 1)]
+        vals = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(steps + 1)] if vb else None
+        swap = torch.empty(n, dtype=kdt, device=dev)
+        vswap = torch.empty(n, dtype=torch.int32, device=dev) if vb else None
+        for i, k in enumerate(keys):
+            if kb == 4:
+                radx_amd.generate_u32(k, seed=1000 + i)
+            else:
+                radx_amd.generate_u64(k, vals[i], seed=1000 + i)
+        s = radx_amd.Sorter(n, kb, vb)
+        s.sort(keys[0], swap, vals[0] if vb else None, vswap)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(1, steps + 1):
+            s.sort(keys[i], swap, vals[i] if vb else None, vswap)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        ok = radx_amd.check_sorted(keys[steps], vals[steps] if vb else None) == 0
+        bytes_per_elem = (kb * 2) * 2 * (kb + vb)  # passes x (read + write) x element bytes
+        res[name] = {"ms_per_sort": round(dt * 1e3, 4), "G_elements_per_s": round(n / dt / 1e9, 3),
+                     "algorithmic_bytes_per_element": bytes_per_elem,
+                     "frac_of_8TBps": round(n / dt * bytes_per_elem / 1e9 / PEAK_HBM_GBPS, 4), "verified": ok}
+        s.close()
+        del keys, vals, swap, vswap
+        torch.cuda.empty_cache()
+    return res
 
 
 def pmc_traffic():
@@ -194,6 +234,12 @@ def main():
     torch.cuda.synchronize()
     copy_gbps = 3 * 2 * batch_bytes / (e0.elapsed_time(e1) / 1e3) / 1e9
 
+    extras = None
+    if world == 1 and not args.no_extras:
+        del pool, work
+        torch.cuda.empty_cache()
+        extras = other_configs(dev)
+
     if rank == 0:
         ms_per_step = elapsed / K * 1e3
         value = world * n * K / elapsed / 1e9
@@ -229,6 +275,8 @@ def main():
                 "launches": scatter_launches, "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if extras is not None:
+            out["other_configs"] = extras
         if world == 1 and not args.no_cpu:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log2n)
         elif world == 1:

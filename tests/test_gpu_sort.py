@@ -413,3 +413,67 @@ def test_index_path_sort_then_gather(device, row_words):
     want = oracle.permutation(cache, hidx)
     assert np.array_equal(d_rows.cpu().numpy().view(np.uint32), want)
     assert np.array_equal(want, rows[np.argsort(keys, kind="stable")])
+
+
+@pytest.mark.parametrize("n", [(1 << 31) + 12345, (1 << 32) - 1])
+def test_largest_sizes_properties(device, n):
+    """Above 2^31 and at the largest element count the 32-bit index arithmetic allows (the
+    reference's NumElements is a 32-bit uniform): sortedness and a preserved multiset checksum.
+    Also the only sizes at which the second-level scan needs more than one round."""
+    import torch
+    import radx_amd
+    k = torch.empty(n, dtype=torch.int32, device=device)
+    swap = torch.empty_like(k)
+    radx_amd.generate_u32(k, seed=77)
+    before = radx_amd.checksum(k)
+    s = radx_amd.Sorter(n)
+    s.sort(k, swap)
+    torch.cuda.synchronize()
+    assert radx_amd.check_sorted(k) == 0
+    assert radx_amd.checksum(k) == before
+    # the extremes of the sorted array against the generator's known range
+    lo, hi = int(k[0].item()) & 0xFFFFFFFF, int(k[-1].item()) & 0xFFFFFFFF
+    assert lo <= hi
+    s.close()
+    del k, swap
+    torch.cuda.empty_cache()
+
+
+def test_config3_2_30_full_equality_vs_cpu(device):
+    """BASELINE config 3 (2^30 uint32, README headline size): bit-exact against the CPU sort."""
+    import torch
+    import radx_amd
+    n = 1 << 30
+    k = torch.empty(n, dtype=torch.int32, device=device)
+    radx_amd.generate_u32(k, seed=5)
+    torch.cuda.synchronize()
+    host = oracle.generate_u32(n, 5)
+    s = radx_amd.Sorter(n)
+    s.sort(k, torch.empty_like(k))
+    torch.cuda.synchronize()
+    got = to_host(k)
+    want = oracle.parallel_sort(host)
+    assert np.array_equal(got, want)
+    s.close()
+
+
+def test_config4_2_28_u64_kv_properties(device):
+    """BASELINE config 4 shape (uint64 key + uint32 payload = original index) at 2^28 pairs:
+    keys sorted, payloads strictly increasing within equal-key runs (stability), every output key
+    equals the input key its payload points to, and the key multiset checksum is preserved."""
+    import torch
+    import radx_amd
+    n = 1 << 28
+    k = torch.empty(n, dtype=torch.int64, device=device)
+    v = torch.empty(n, dtype=torch.int32, device=device)
+    radx_amd.generate_u64(k, v, seed=9)
+    k &= 0x0000FFFFFFFF0000 | (0xFF << 56)  # thin the key space so equal keys occur
+    orig = k.clone()
+    before = radx_amd.checksum(k)
+    s = radx_amd.Sorter(n, 8, 4)
+    s.sort(k, torch.empty_like(k), v, torch.empty_like(v))
+    torch.cuda.synchronize()
+    assert radx_amd.check_sorted(k, v) == 0          # order + stability (payload = input index)
+    assert radx_amd.checksum(k) == before
+    assert bool((orig[v.long()] == k).all().item())  # keys_in[payload[i]] == keys_out[i]
+    s.close()
