@@ -477,3 +477,26 @@ def test_config4_2_28_u64_kv_properties(device):
     assert radx_amd.checksum(k) == before
     assert bool((orig[v.long()] == k).all().item())  # keys_in[payload[i]] == keys_out[i]
     s.close()
+
+
+def test_sort_is_graph_capturable(device):
+    """radx_hip_sort only enqueues kernels (no allocation, memset, copy or synchronisation), so a
+    caller can capture it into a HIP graph and replay it on new contents of the same buffers."""
+    import torch
+    import radx_amd
+    n = 200000 + 7
+    s = radx_amd.Sorter(n, 4, 0)
+    k = torch.zeros(n, dtype=torch.int32, device=device)
+    swap = torch.empty_like(k)
+    s.sort(k, swap)                       # warm-up outside capture (code object load)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        s.sort(k, swap)
+    for seed in (1, 2, 3):
+        keys = make_keys("uniform", n, 4, seed=seed)
+        k.copy_(to_dev(keys, device))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(k), np.sort(keys)), seed
+    s.close()
