@@ -66,7 +66,7 @@ def cpu_baseline(log2n):
 
 
 def other_configs(dev):
-    """The other single-GPU BASELINE.json configs, timed the same way (every step its own
+    """The other single-GPU benchmark configurations, timed the same way (every step its own
     pre-generated batch, wall clock between synchronisations).  Reported beside the headline
     line, never as `value`."""
     import torch

@@ -1,7 +1,7 @@
 // cpu_sort.cpp — the reference's CPU comparator, restated, plus the parallel std::sort baseline.
 //
-// TEST / BASELINE INFRASTRUCTURE ONLY (see radx_oracle.h): used by tests, by the harness's
-// CPU path and by bench.py's cpu_baseline leg; never by the HIP engine.
+// TEST AND CPU-BASELINE INFRASTRUCTURE ONLY (see radx_oracle.h): used by the tests and by bench.py's
+// cpu_baseline leg; never by the HIP engine or the harness (which carries its own CPU timing leg).
 //
 // The reference compares its GPU sort against
 //     std::stable_sort(std::execution::par, begin, end)        src/test/sort.cpp:218-219

@@ -1,5 +1,5 @@
 """CPU-side checks of the drop-in boundary: the C-ABI library loads without a GPU, exports every
-symbol include/radx_hip.h declares, reports argument errors, and the harness's CPU path (BASELINE
+symbol include/radx_hip.h declares, reports argument errors, and the harness's CPU path (the no-GPU benchmark
 config 1: 1 Mi uniform uint32 keys, parallel std::sort, no GPU) runs and passes."""
 import ctypes
 import json

@@ -276,7 +276,7 @@ def test_medium_2_24_vs_cpu(device):
 
 
 def test_full_size_2_28_properties(device):
-    """BASELINE config 2 (2^28 uint32) through size-independent properties: sortedness and a
+    """The 2^28-key uint32 benchmark configuration through size-independent properties: sortedness and a
     preserved multiset checksum; plus exact equality on a strided sample against numpy."""
     import torch
     import radx_amd
@@ -440,7 +440,7 @@ def test_largest_sizes_properties(device, n):
 
 
 def test_config3_2_30_full_equality_vs_cpu(device):
-    """BASELINE config 3 (2^30 uint32, README headline size): bit-exact against the CPU sort."""
+    """The 2^30-key uint32 configuration (the reference README's headline size): bit-exact against the CPU sort."""
     import torch
     import radx_amd
     n = 1 << 30
@@ -458,7 +458,7 @@ def test_config3_2_30_full_equality_vs_cpu(device):
 
 
 def test_config4_2_28_u64_kv_properties(device):
-    """BASELINE config 4 shape (uint64 key + uint32 payload = original index) at 2^28 pairs:
+    """The key-value benchmark shape (uint64 key + uint32 payload = original index) at 2^28 pairs:
     keys sorted, payloads strictly increasing within equal-key runs (stability), every output key
     equals the input key its payload points to, and the key multiset checksum is preserved."""
     import torch

@@ -1,5 +1,5 @@
 #!/bin/bash
-# BASELINE.json configs 2-4 through tools/quick_bench.py; output collected in gpurun_out/config_sweep.txt
+# The single-GPU benchmark configurations through tools/quick_bench.py; output collected in gpurun_out/config_sweep.txt
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/config_sweep.txt
 : > "$OUT"

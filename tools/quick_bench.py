@@ -1,18 +1,16 @@
-"""Development timing loop: sort 2^LOG2N hashed uint32 keys a few times, print per-kernel times."""
+"""Development timing loop: sort 2^LOG2N hashed keys a few times and print per-kernel times.
+
+  python tools/quick_bench.py [log2n=28] [iters=5] [key_bytes=4] [value_bytes=0] [fuse=1]
+"""
 import sys
-import time
 
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import radx_amd
 
-log2n = int(sys.argv[1]) if len(sys.argv) > 1 else 28
-iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-kb = int(sys.argv[3]) if len(sys.argv) > 3 else 4
-vb = int(sys.argv[4]) if len(sys.argv) > 4 else 0
-tpb = int(sys.argv[5]) if len(sys.argv) > 5 else 4
-fuse = int(sys.argv[6]) if len(sys.argv) > 6 else 1
+arg = lambda i, d: int(sys.argv[i]) if len(sys.argv) > i else d
+log2n, iters, kb, vb, fuse = arg(1, 28), arg(2, 5), arg(3, 4), arg(4, 0), arg(5, 1)
 n = 1 << log2n
 dev = torch.device("cuda:0")
 kdt = torch.int32 if kb == 4 else torch.int64
@@ -25,7 +23,6 @@ if vb:
 s = radx_amd.Sorter(n, kb, vb)
 s.tune(bool(fuse))
 s.profile(True)
-print("tiles_per_block", tpb, "fuse", fuse)
 passes = kb * 2
 for it in range(iters):
     if kb == 4:
@@ -45,5 +42,4 @@ for it in range(iters):
           % (log2n, it, ms, n / ms / 1e6, bytes_alg / ms / 1e6, bytes_alg / ms / 1e6 / 80.0,
              t["hist"][0] / max(1, t["hist"][1]), t["scan"][0] / max(1, t["scan"][1]),
              t["scatter"][0] / max(1, t["scatter"][1])), flush=True)
-bad = radx_amd.check_sorted(k, v)
-print("violations:", bad)
+print("violations:", radx_amd.check_sorted(k, v))
