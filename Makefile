@@ -34,7 +34,12 @@ resources:
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null radx_amd/csrc/radx_hip.hip 2>&1 | \
 	    grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" | grep -v "^$$" || true
 
-clean:
-	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS)
+# development micro-benchmark: HBM copy ceilings by access width and launch shape
+micro: tools/micro/copy_bench
+tools/micro/copy_bench: tools/micro/copy_bench.hip
+	$(HIPCC) -O3 -w --offload-arch=$(ARCH) -o $@ $<
 
-.PHONY: all clean resources
+clean:
+	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) tools/micro/copy_bench
+
+.PHONY: all clean resources micro
