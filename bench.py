@@ -5,8 +5,8 @@
 
 One step = one complete sort (all 8 four-bit passes) of one batch of 2^L uniform uint32 keys
 per GPU that is already resident in HBM.  N > 1 is launched by torch.distributed.run, one rank
-per GPU; a step is then MSD split + one all-to-all-v over RCCL + the local passes, and the
-per-GPU batch stays 2^L (weak scaling).  Every step sorts a DIFFERENT pre-generated batch, so
+per GPU; a step is then the split pass on the top digit + the all-to-all-v exchange over RCCL +
+the 7 local passes, pipelined per sub-bucket, and the per-GPU batch stays 2^L (weak scaling).  Every step sorts a DIFFERENT pre-generated batch, so
 no step ever sees already-sorted input.  Rank 0 prints one JSON line.
 """
 import argparse
@@ -119,7 +119,7 @@ def main():
     import torch
     import torch.distributed as dist
     import radx_amd
-    from radx_amd.sharded import HipEngine, ShardedSorter
+    from radx_amd.sharded import HipEngine, ShardedSorter, init_process_group
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,19 +133,20 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        init_process_group(dev)
 
     n = 1 << args.log2n
     K, W = args.steps, args.warmup
     cap = n if world == 1 else ShardedSorter.suggest_capacity(n)
     batch_bytes = cap * 4
     free_b, _ = torch.cuda.mem_get_info(dev)
-    budget = int(free_b * 0.75) - 2 * batch_bytes
+    budget = int(free_b * 0.75) - 3 * batch_bytes
     pool_n = max(1, min(K + W, budget // batch_bytes))
     wall_mode = pool_n >= K + W
 
     pool = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(pool_n)]
     work = torch.empty(cap, dtype=torch.int32, device=dev)
+    stage = torch.empty(cap, dtype=torch.int32, device=dev) if world > 1 else None
 
     def fill(i, step):
         radx_amd.generate_u32(pool[i], seed=(step + 1) * 7919 + rank * 104729, n=n)
@@ -160,7 +161,7 @@ def main():
         if world == 1:
             engine.sorter.sort(pool[i], work, n=n)
             return n
-        return sharder.sort(pool[i], work, n)[1]
+        return sharder.sort(pool[i], work, n, stage)[1]
 
     def fence():
         torch.cuda.synchronize()
@@ -244,10 +245,10 @@ def main():
         ms_per_step = elapsed / K * 1e3
         value = world * n * K / elapsed / 1e9
         scatter_ms, scatter_launches = kt["scatter"]
-        # algorithmic bytes of one scatter launch: every key read once and written once
-        # (on N > 1 the shard length varies by a fraction of a percent around n)
-        alg_bytes = 2.0 * 4 * n
+        # algorithmic bytes of the scatter launches: every pass reads and writes every key once.
+        # One launch covers n keys on one GPU and one region (n * N / 16 keys on average) on N > 1.
         avg_ms = scatter_ms / max(1, scatter_launches)
+        alg_bytes = 8 * 2.0 * 4 * n * K / max(1, scatter_launches)
         achieved = alg_bytes / (avg_ms / 1e3) / 1e9 if avg_ms > 0 else 0.0
         traffic = pmc_traffic()
         out = {
@@ -258,8 +259,8 @@ def main():
             "config": {
                 "workload": "2^%d uniform (hashed) uint32 keys per GPU, full sort = 8 x 4-bit LSD passes%s"
                             % (args.log2n, "" if world == 1 else
-                               ", MSD split on the top %d bits + one RCCL all-to-all-v + local passes"
-                               % (world.bit_length() - 1)),
+                               ", split pass on the top digit + RCCL all-to-all-v exchange in %d "
+                               "sub-buckets overlapped with the 7 local passes" % (16 // world)),
                 "keys_per_gpu": n, "total_keys": n * world, "key_bytes": 4, "passes": 8,
                 "parallelism": "1 GPU" if world == 1 else "msd-shard x%d" % world},
             "verified": verified, "timing": timing,

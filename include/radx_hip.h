@@ -87,6 +87,34 @@ int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* va
                        void* vals_swap, uint64_t n, int begin_bit, int end_bit, void* stream);
 
 /*
+ * As radx_hip_sort_bits, with exactly ceil((end_bit-begin_bit)/4) passes (at least one; no
+ * padding pass) and the last pass storing to keys_out / vals_out instead of its ping-pong
+ * partner.  keys / keys_swap (16-byte aligned) are both overwritten.  keys_out needs only the
+ * alignment of one key and may lie anywhere that does not overlap the buffer the last pass
+ * reads (keys for an odd pass count, keys_swap for an even one) — e.g. inside a larger array
+ * at an arbitrary element offset.  The reference's passes always alternate between its two
+ * fixed buffers (shaders-sdk/radix/scattering.comp:40,143); this is what a caller that sorts
+ * several independent segments into one packed array needs (the multi-GPU path).
+ */
+int radx_hip_sort_bits_into(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals,
+                            void* vals_swap, uint64_t n, int begin_bit, int end_bit,
+                            void* keys_out, void* vals_out, void* stream);
+
+/*
+ * The split step of a sort spread over 2^log2_ranks GPUs (no counterpart in the single-device
+ * reference; it is one histogram -> scan -> scatter pass of the same kernels, as dispatched by
+ * include/radx/radx_implement.inl:427-444).  Stable partition of n elements on the key's top
+ * 4-bit digit d = (destination rank r << (4 - log2_ranks)) | sub-bucket j, written in
+ * (j, r) order: bucket (j, r) is the run at position p = j * 2^log2_ranks + r, so that for
+ * every j the runs for all destination ranks are adjacent, in rank order — one contiguous
+ * all-to-all send buffer per sub-bucket.  radx_hip_digit_starts then returns the 16 run starts
+ * indexed by p.  The sorter's key order (radx_hip_set_key_order) applies to the digit; the keys
+ * are stored with their own bits.
+ */
+int radx_hip_msd_split(radx_hip_sorter* s, const void* keys_in, void* keys_out, const void* vals_in,
+                       void* vals_out, uint64_t n, int log2_ranks, void* stream);
+
+/*
  * Enqueue ONE pass (histogram -> scan -> scatter) reading keys_in / vals_in and writing
  * keys_out / vals_out, on the digit of `num_bits` (0..4) bits starting at bit `bit`.
  * The tables stay in the sorter's scratch until the next call.

@@ -24,6 +24,9 @@ SIGNATURES = {
     "radx_hip_sort": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp]),
     "radx_hip_sort_bits": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,
                                           ctypes.c_int, _vp]),
+    "radx_hip_sort_bits_into": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,
+                                               ctypes.c_int, _vp, _vp, _vp]),
+    "radx_hip_msd_split": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int, _vp]),
     "radx_hip_pass": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,
                                      ctypes.c_int, _vp]),
     "radx_hip_pass_fused": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,

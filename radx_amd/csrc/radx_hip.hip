@@ -77,8 +77,18 @@ __device__ __forceinline__ uint32_t digit_of(K key, int bit, uint32_t mask) {
 // to the unsigned integer with the same rank as it is loaded by the first pass and maps it back
 // as the last pass stores it, so no extra traffic.  mode bits: 1 two's-complement signed,
 // 2 IEEE float (total order by sign and magnitude: -NaN < -inf < ... < -0 < +0 < ... < +inf < +NaN),
-// 4 descending.
-constexpr int kOrderSigned = 1, kOrderFloat = 2, kOrderDescending = 4;
+// 4 descending.  Bits 4-5 (the multi-GPU split only): rotate the image's top 4-bit digit left by
+// that many bits, so that a digit made of (destination rank, sub-bucket) sorts as
+// (sub-bucket, destination rank).
+constexpr int kOrderSigned = 1, kOrderFloat = 2, kOrderDescending = 4, kOrderRotShift = 4;
+
+template <typename K>
+__host__ __device__ __forceinline__ K rotate_top_digit(K k, int r) {
+    constexpr int SH = sizeof(K) * 8 - 4;
+    const uint32_t top = static_cast<uint32_t>(k >> SH);
+    const uint32_t rot = ((top << r) | (top >> (4 - r))) & 15u;
+    return static_cast<K>((k & ((static_cast<K>(1) << SH) - 1)) | (static_cast<K>(rot) << SH));
+}
 
 template <typename K>
 __host__ __device__ __forceinline__ K key_to_ordered(K k, int mode) {
@@ -87,12 +97,14 @@ __host__ __device__ __forceinline__ K key_to_ordered(K k, int mode) {
     if (mode & kOrderFloat) k ^= ((k >> TOP) ? static_cast<K>(~static_cast<K>(0)) : SIGN);
     else if (mode & kOrderSigned) k ^= SIGN;
     if (mode & kOrderDescending) k = static_cast<K>(~k);
+    if (const int r = (mode >> kOrderRotShift) & 3) k = rotate_top_digit<K>(k, r);
     return k;
 }
 template <typename K>
 __host__ __device__ __forceinline__ K ordered_to_key(K k, int mode) {
     constexpr int TOP = sizeof(K) * 8 - 1;
     constexpr K SIGN = static_cast<K>(1) << TOP;
+    if (const int r = (mode >> kOrderRotShift) & 3) k = rotate_top_digit<K>(k, 4 - r);
     if (mode & kOrderDescending) k = static_cast<K>(~k);
     if (mode & kOrderFloat) k ^= ((k >> TOP) ? SIGN : static_cast<K>(~static_cast<K>(0)));
     else if (mode & kOrderSigned) k ^= SIGN;
@@ -174,9 +186,13 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
         for (int m = 0; m < kThreadDwords / 4; ++m) {
             K k[PER_VEC];
             unpack4<K>(v[m], k);
+            if (order_in) {
+#pragma unroll
+                for (int j = 0; j < PER_VEC; ++j) k[j] = key_to_ordered<K>(k[j], order_in);
+            }
 #pragma unroll
             for (int j = 0; j < PER_VEC; ++j) {
-                const uint32_t d = digit_of<K>(key_to_ordered<K>(k[j], order_in), bit, mask);
+                const uint32_t d = digit_of<K>(k[j], bit, mask);
                 __hip_atomic_fetch_add(&bins[d * 32u + col], 1u, __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_WORKGROUP);
             }
@@ -951,16 +967,16 @@ int radx_hip_pass_fused(radx_hip_sorter* s, const void* keys_in, void* keys_out,
     return run_pass(s, a, static_cast<hipStream_t>(stream));
 }
 
-int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, void* vals_swap,
-                       uint64_t n, int begin_bit, int end_bit, void* stream) {
-    if (const int rc = check_buffers(s, keys, keys_swap, vals, vals_swap, n)) return rc;
-    if (begin_bit < 0 || end_bit > s->key_bytes * 8 || begin_bit > end_bit)
-        return bad_arg("need 0 <= begin_bit <= end_bit <= key bits");
-    if (n == 0) return 0;
-    DeviceGuard guard(s->device);
-    RADX_TRY(guard.status());
+namespace {
+// The pass loop behind radx_hip_sort_bits / radx_hip_sort_bits_into.  keys_out == nullptr: the pass
+// count is rounded up to even (a zero-width digit pass is a stable copy) so that the result ends
+// in `keys`.  Otherwise exactly ceil(bits / 4) passes (at least one) run and the last one stores
+// to keys_out / vals_out instead of its ping-pong partner.
+int sort_bits_impl(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, void* vals_swap, uint64_t n,
+                   int begin_bit, int end_bit, void* keys_out, void* vals_out, hipStream_t stream) {
     int passes = (end_bit - begin_bit + kDigitBits - 1) / kDigitBits;
-    passes += passes & 1;  // even, so the result ends in `keys` (scattering.comp:40,143)
+    if (keys_out) passes = passes ? passes : 1;
+    else passes += passes & 1;  // even, so the result ends in `keys` (scattering.comp:40,143)
     void* kbuf[2] = {keys, keys_swap};
     void* vbuf[2] = {vals, vals_swap};
     auto digit_at = [&](int p, int* bit, int* width) {
@@ -973,17 +989,78 @@ int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* va
         PassArgs a{};
         digit_at(p, &a.bit, &a.num_bits);
         const int src = p & 1, dstb = 1 - src;
-        a.kin = kbuf[src]; a.kout = kbuf[dstb]; a.vin = vbuf[src]; a.vout = vbuf[dstb];
+        const bool last = p == passes - 1;
+        a.kin = kbuf[src]; a.vin = vbuf[src];
+        a.kout = last && keys_out ? keys_out : kbuf[dstb];
+        a.vout = last && keys_out ? vals_out : vbuf[dstb];
         a.n = static_cast<uint32_t>(n);
         a.have_counts = s->fuse && p > 0;
-        a.fuse_next = s->fuse && p + 1 < passes;
+        a.fuse_next = s->fuse && !last;
         if (a.fuse_next) digit_at(p + 1, &a.next_bit, &a.next_num_bits);
         a.order_in = p == 0 ? s->key_order : 0;
-        a.order_out = p == passes - 1 ? s->key_order : 0;
-        if (const int rc = run_pass(s, a, static_cast<hipStream_t>(stream))) return rc;
+        a.order_out = last ? s->key_order : 0;
+        if (const int rc = run_pass(s, a, stream)) return rc;
     }
     s->chained = false;
     return 0;
+}
+
+bool ranges_overlap(const void* a, const void* b, uint64_t bytes) {
+    const uintptr_t x = reinterpret_cast<uintptr_t>(a), y = reinterpret_cast<uintptr_t>(b);
+    return x < y + bytes && y < x + bytes;
+}
+}  // namespace
+
+int radx_hip_sort_bits(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, void* vals_swap,
+                       uint64_t n, int begin_bit, int end_bit, void* stream) {
+    if (const int rc = check_buffers(s, keys, keys_swap, vals, vals_swap, n)) return rc;
+    if (begin_bit < 0 || end_bit > s->key_bytes * 8 || begin_bit > end_bit)
+        return bad_arg("need 0 <= begin_bit <= end_bit <= key bits");
+    if (n == 0) return 0;
+    DeviceGuard guard(s->device);
+    RADX_TRY(guard.status());
+    return sort_bits_impl(s, keys, keys_swap, vals, vals_swap, n, begin_bit, end_bit, nullptr, nullptr,
+                          static_cast<hipStream_t>(stream));
+}
+
+int radx_hip_sort_bits_into(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, void* vals_swap,
+                            uint64_t n, int begin_bit, int end_bit, void* keys_out, void* vals_out,
+                            void* stream) {
+    if (const int rc = check_buffers(s, keys, keys_swap, vals, vals_swap, n)) return rc;
+    if (begin_bit < 0 || end_bit > s->key_bytes * 8 || begin_bit > end_bit)
+        return bad_arg("need 0 <= begin_bit <= end_bit <= key bits");
+    if (n == 0) return 0;
+    if (!keys_out) return bad_arg("keys_out is NULL");
+    if (reinterpret_cast<uintptr_t>(keys_out) % s->key_bytes) return bad_arg("keys_out is not aligned to the key size");
+    if (s->value_bytes) {
+        if (!vals_out) return bad_arg("vals_out is NULL for a key-value sorter");
+        if (reinterpret_cast<uintptr_t>(vals_out) % 4) return bad_arg("vals_out is not 4-byte aligned");
+    }
+    int passes = (end_bit - begin_bit + kDigitBits - 1) / kDigitBits;
+    if (passes == 0) passes = 1;
+    // the last pass reads keys (odd pass count) or keys_swap (even): its output must not touch its input
+    const void* last_src = (passes & 1) ? keys : keys_swap;
+    if (ranges_overlap(keys_out, last_src, n * s->key_bytes))
+        return bad_arg("keys_out overlaps the buffer the last pass reads");
+    if (s->value_bytes && ranges_overlap(vals_out, (passes & 1) ? vals : vals_swap, n * 4))
+        return bad_arg("vals_out overlaps the buffer the last pass reads");
+    DeviceGuard guard(s->device);
+    RADX_TRY(guard.status());
+    return sort_bits_impl(s, keys, keys_swap, vals, vals_swap, n, begin_bit, end_bit, keys_out, vals_out,
+                          static_cast<hipStream_t>(stream));
+}
+
+int radx_hip_msd_split(radx_hip_sorter* s, const void* keys_in, void* keys_out, const void* vals_in,
+                       void* vals_out, uint64_t n, int log2_ranks, void* stream) {
+    if (const int rc = check_buffers(s, keys_in, keys_out, vals_in, vals_out, n)) return rc;
+    if (log2_ranks < 0 || log2_ranks > kDigitBits) return bad_arg("log2_ranks must be 0..4");
+    if (n == 0) return 0;
+    DeviceGuard guard(s->device);
+    RADX_TRY(guard.status());
+    const int order = s->key_order | ((log2_ranks & 3) << kOrderRotShift);  // rotating by 0 or 4 is the identity
+    PassArgs a{keys_in, keys_out, vals_in, vals_out, static_cast<uint32_t>(n), s->key_bytes * 8 - kDigitBits,
+               kDigitBits, false, false, 0, 0, order, order};
+    return run_pass(s, a, static_cast<hipStream_t>(stream));
 }
 
 int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, void* vals_swap,

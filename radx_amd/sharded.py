@@ -1,42 +1,69 @@
-"""Sort keys that are spread over the GPUs of one node: most-significant-digit split, one
-all-to-all-v over RCCL/xGMI, then an independent local LSD sort per GPU.
+"""Sort keys that are spread over the GPUs of one node: one split pass on the most significant
+4-bit digit, the exchange over RCCL/xGMI, then independent local LSD passes on the remaining bits.
 
-The reference is single-device (no collective anywhere in it); this is the one exchange step
-a multi-GPU radix sort needs.  One process per GPU, torch.distributed with backend "nccl"
-(RCCL).  After `sort`, rank r holds the ascending sorted run of every key whose top
-log2(world) bits equal r; the concatenation of the ranks' shards in rank order is the sorted
-whole.
+The reference is single-device (no collective anywhere in it); this is the one exchange step a
+multi-GPU radix sort needs, placed between the first pass and the other passes of the same
+8-pass (uint32) sort: a sort over G GPUs runs exactly as many passes over every key as a sort on
+one GPU.  One process per GPU, torch.distributed with backend "nccl" (RCCL).  After `sort`, rank r
+holds the ascending sorted run of every key whose top log2(G) bits equal r; the concatenation of
+the ranks' shards in rank order is the sorted whole.
 
-Per rank, with G = world size and b = log2 G:
-  1. split     one scatter pass on the top b key bits (the same histogram/scan/scatter kernels,
-               digit width b): `work` receives the keys grouped by destination rank, stably;
-  2. counts    all_gather of the G send counts -> every rank knows what it will receive;
-  3. exchange  ONE all_to_all_single with uneven splits, segment j -> rank j.  xGMI is
-               point-to-point, each peer pair has its own link, so the exchange runs at
-               (n/G * key bytes) / link rate, all 7 links busy at once;
-  4. local     LSD passes over the low (key bits - b) bits; the top b bits are constant in a shard.
+Per rank, with G = world size, b = log2 G and S = 16 / G sub-buckets per rank:
+  1. split     one scatter pass on the top 4-bit digit d = (destination rank r, sub-bucket j), the
+               16 runs written in (j, r) order into `work`: for every j the runs for all
+               destination ranks are adjacent.
+  2. counts    all_gather of the 16 run lengths -> every rank knows what it will receive.
+  3. exchange  S all-to-all-v's, issued back to back on RCCL's stream: number j sends sub-bucket j
+               of every destination rank and lands, grouped by source, in region j of `stage`.
+               xGMI is point-to-point, each peer pair has its own link, so the exchange as a whole
+               runs at (n/G * key bytes) / link rate with all G-1 links busy at once.
+  4. local     as soon as all-to-all j has landed, region j — all of its keys share their top
+               digit — is sorted on the low (key bits - 4) bits while all-to-all j+1.. are still
+               in flight; the last pass of region j stores straight to the region's final place
+               in `keys`, so the shard comes out packed.
+
+Region j of `stage` starts at a 16-byte aligned offset (the kernels load 16 bytes at a time);
+its final place in `keys` is the exact prefix sum of the region lengths.  The passes of region j
+alternate between stage[c_j:] and keys[c_j:] with c_j >= that prefix sum, so they never touch
+the finished regions 0..j-1.
 
 The engine is injected so the exchange logic can be exercised on CPU tensors over gloo by the
 tests; the product engine is HipEngine (the C ABI).  There is no CPU fallback in this module.
 """
 import numpy as np
 
+SPLIT_BITS = 4  # the split pass always takes one whole 4-bit digit
+
+
+def init_process_group(device, **kwargs):
+    """torch.distributed over RCCL for one rank per GPU, rank / world size / rendezvous from the
+    environment torch.distributed.run sets (or from kwargs).  RCCL's stream gets high priority so
+    that an exchange in flight keeps its workgroups scheduled while local sort passes, which fill
+    every CU, run beside it."""
+    import torch.distributed as dist
+    options = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group("nccl", device_id=device, pg_options=options, **kwargs)
+
 
 class HipEngine:
-    """split / local sort through libradx_hip.so on the current device."""
+    """split / local sort through libradx_hip.so on one device."""
 
     def __init__(self, capacity, key_bytes=4, device=0):
         from .sorter import Sorter
         self.key_bytes = key_bytes
         self.sorter = Sorter(capacity, key_bytes, 0, device)
 
-    def split(self, src, dst, n, bit, num_bits):
-        """Stable partition of src[:n] into dst[:n] by the digit at `bit`; returns the 16 run starts + n."""
-        self.sorter.run_pass(src, dst, bit=bit, num_bits=num_bits, n=n)
+    def msd_split(self, src, dst, n, log2_ranks):
+        """Stable partition of src[:n] into dst[:n] on the top digit, runs in (sub-bucket, rank)
+        order; returns the 16 run starts followed by n."""
+        self.sorter.msd_split(src, dst, log2_ranks, n=n)
         return self.sorter.digit_starts()
 
     def sort_bits(self, keys, swap, n, begin_bit, end_bit):
         self.sorter.sort_bits(keys, swap, begin_bit, end_bit, n=n)
+
+    def sort_bits_into(self, keys, swap, out, n, begin_bit, end_bit):
+        self.sorter.sort_bits_into(keys, swap, out, begin_bit, end_bit, n=n)
 
     def close(self):
         self.sorter.close()
@@ -45,13 +72,15 @@ class HipEngine:
 class ShardedSorter:
     """Sorts `n_local` keys per rank across the process group.
 
-    keys / work are caller-owned device buffers of `capacity` elements each
-    (capacity >= n_local and >= the shard this rank ends up with; `suggest_capacity`
-    gives n_local plus slack for near-uniform keys).  The shard is returned as a view of `keys`.
+    keys / work / stage are caller-owned device buffers of `capacity` elements each
+    (capacity >= n_local and >= the shard this rank ends up with plus a few elements of
+    alignment padding; `suggest_capacity` gives n_local plus slack for near-uniform keys).
+    `stage` is allocated on first use when not given.  The shard is returned as a view of `keys`.
     """
 
-    def __init__(self, engine, group=None, key_bits=32):
-        import torch.distributed as dist
+    def __init__(self, engine, group=None, key_bits=32, exchange_when_alone=False, dist=None):
+        if dist is None:  # anything with torch.distributed's collectives can be injected instead
+            import torch.distributed as dist
         self.dist = dist
         self.engine = engine
         self.group = group
@@ -59,43 +88,76 @@ class ShardedSorter:
         self.rank = dist.get_rank(group)
         if self.world & (self.world - 1) or self.world > 16:
             raise ValueError("world size must be a power of two <= 16 (one 4-bit digit), got %d" % self.world)
-        self.split_bits = self.world.bit_length() - 1
+        self.log2_world = self.world.bit_length() - 1
         self.key_bits = key_bits
+        self.align = 16 // (key_bits // 8)  # elements per 16 bytes
+        # a world of one normally skips split and exchange; the tests switch them on to drive
+        # the whole pipeline through the real backend on a single GPU
+        self.exchange_when_alone = exchange_when_alone
+        self._stage = None
 
     @staticmethod
     def suggest_capacity(n_local, slack=0.05):
         return int(n_local * (1.0 + slack)) + 4096
 
-    def sort(self, keys, work, n_local):
+    def plan(self, matrix):
+        """From the gathered [source][16] run lengths: per sub-bucket j the receive counts by source,
+        the region length, its exact start in the packed shard and its aligned start in `stage`."""
+        G, S, a = self.world, 16 // self.world, self.align
+        recv = np.stack([matrix[:, j * G + self.rank] for j in range(S)])  # [j][source]
+        length = recv.sum(axis=1)
+        exact = np.concatenate([[0], np.cumsum(length)[:-1]])
+        staged = np.zeros(S, dtype=np.int64)
+        for j in range(1, S):
+            staged[j] = -(-(staged[j - 1] + length[j - 1]) // a) * a
+        return recv, length, exact, staged
+
+    def sort(self, keys, work, n_local, stage=None):
         """Returns (shard_view_of_keys, shard_len, send_counts[G], recv_counts[G])."""
         import torch
-        G, b = self.world, self.split_bits
+        G, b = self.world, self.log2_world
         if keys.numel() < n_local or work.numel() < n_local:
             raise ValueError("keys/work hold fewer than n_local elements")
-        if G == 1:
+        if G == 1 and not self.exchange_when_alone:
             self.engine.sort_bits(keys, work, n_local, 0, self.key_bits)
             return keys[:n_local], n_local, np.array([n_local]), np.array([n_local])
+        if stage is None:
+            if self._stage is None or self._stage.numel() < keys.numel() or self._stage.device != keys.device:
+                self._stage = torch.empty_like(keys)
+            stage = self._stage
+        S = 16 // G
 
-        # 1. stable split by destination rank: keys -> work
-        starts = self.engine.split(keys, work, n_local, self.key_bits - b, b)
-        send = np.diff(starts[:G + 1].astype(np.int64))
-        send[G - 1] = n_local - int(starts[G - 1])  # digits >= G do not occur; the last run ends at n
+        # 1. stable split on the top digit: keys -> work, runs in (sub-bucket, destination rank) order
+        starts = self.engine.msd_split(keys, work, n_local, b).astype(np.int64)
+        runs = np.diff(starts)  # 16 run lengths; starts[16] == n_local
 
-        # 2. every rank learns the whole G x G count matrix
-        mine = torch.tensor(send, dtype=torch.int64, device=keys.device)
-        matrix = torch.empty(G * G, dtype=torch.int64, device=keys.device)
+        # 2. every rank learns the whole [source][16] matrix of run lengths
+        mine = torch.tensor(runs, dtype=torch.int64, device=keys.device)
+        matrix = torch.empty(G * 16, dtype=torch.int64, device=keys.device)
         self.dist.all_gather_into_tensor(matrix, mine, group=self.group)
-        matrix = matrix.cpu().numpy().reshape(G, G)  # [src][dst]
-        recv = matrix[:, self.rank].copy()
-        total = int(recv.sum())
-        if total > keys.numel() or total > work.numel():
-            raise RuntimeError("rank %d receives %d keys but its buffers hold %d: allocate more slack"
-                               % (self.rank, total, min(keys.numel(), work.numel())))
+        matrix = matrix.cpu().numpy().reshape(G, 16)
+        recv, length, exact, staged = self.plan(matrix)
+        total = int(length.sum())
+        need = int(staged[-1] + length[-1])
+        if need > keys.numel() or need > stage.numel():
+            raise RuntimeError("rank %d receives %d keys (%d with alignment padding) but its buffers hold %d: "
+                               "allocate more slack" % (self.rank, total, need, min(keys.numel(), stage.numel())))
 
-        # 3. the one exchange: work (grouped by destination) -> keys (grouped by source)
-        self.dist.all_to_all_single(keys[:total], work[:n_local], output_split_sizes=recv.tolist(),
-                                    input_split_sizes=send.tolist(), group=self.group)
+        # 3. the exchange, one all-to-all-v per sub-bucket, all in flight at once
+        pending = []
+        for j in range(S):
+            lo, hi = int(starts[j * G]), int(starts[(j + 1) * G])
+            c, m = int(staged[j]), int(length[j])
+            pending.append(self.dist.all_to_all_single(
+                stage[c:c + m], work[lo:hi], output_split_sizes=recv[j].tolist(),
+                input_split_sizes=runs[j * G:(j + 1) * G].tolist(), group=self.group, async_op=True))
 
-        # 4. local LSD sort of the shard; its top b bits are all == rank
-        self.engine.sort_bits(keys, work, total, 0, self.key_bits - b)
-        return keys[:total], total, send, recv
+        # 4. local LSD passes per region as it lands; the last pass packs it into keys[exact[j]:]
+        low_bits = self.key_bits - SPLIT_BITS
+        for j in range(S):
+            pending[j].wait()
+            c, m = int(staged[j]), int(length[j])
+            if m:
+                self.engine.sort_bits_into(stage[c:], keys[c:], keys[int(exact[j]):], m, 0, low_bits)
+        send = runs.reshape(S, G).sum(axis=0)
+        return keys[:total], total, send, recv.sum(axis=0)

@@ -77,6 +77,23 @@ class Sorter:
                                                _ptr(vals_swap), n, begin_bit, end_bit,
                                                _stream(stream, self.device)))
 
+    def sort_bits_into(self, keys, swap, keys_out, begin_bit, end_bit, vals=None, vals_swap=None,
+                       vals_out=None, n=None, stream=None):
+        """sort_bits with exactly ceil(bits/4) passes; the last one stores to keys_out (any key-aligned
+        address that does not overlap the last pass's source)."""
+        n = self._args(keys, swap, vals, vals_swap, n)
+        self._check(keys_out, self.key_bytes, n, "keys_out")
+        self._check(vals_out, 4, n, "vals_out")
+        capi.check(capi.lib.radx_hip_sort_bits_into(self._h, _ptr(keys), _ptr(swap), _ptr(vals),
+                                                    _ptr(vals_swap), n, begin_bit, end_bit, _ptr(keys_out),
+                                                    _ptr(vals_out), _stream(stream, self.device)))
+
+    def msd_split(self, keys_in, keys_out, log2_ranks, vals_in=None, vals_out=None, n=None, stream=None):
+        """Stable partition on the top 4-bit digit, buckets in (sub-bucket, destination rank) order."""
+        n = self._args(keys_in, keys_out, vals_in, vals_out, n)
+        capi.check(capi.lib.radx_hip_msd_split(self._h, _ptr(keys_in), _ptr(keys_out), _ptr(vals_in),
+                                               _ptr(vals_out), n, log2_ranks, _stream(stream, self.device)))
+
     def run_pass(self, keys_in, keys_out, bit, num_bits=4, vals_in=None, vals_out=None, n=None, stream=None):
         n = self._args(keys_in, keys_out, vals_in, vals_out, n)
         capi.check(capi.lib.radx_hip_pass(self._h, _ptr(keys_in), _ptr(keys_out), _ptr(vals_in),

@@ -293,46 +293,6 @@ def test_full_size_2_28_properties(device):
     s.close()
 
 
-@pytest.mark.parametrize("world", [2, 4, 8, 16])
-def test_sharded_pipeline_single_process(device, world):
-    """The GPU side of the multi-GPU path without a process group: every 'rank' splits its keys by
-    the top log2(world) bits (HipEngine.split), the segments are exchanged by plain copies in the
-    all-to-all-v pattern, and every shard is sorted on the remaining bits (HipEngine.sort_bits)."""
-    import torch
-    from radx_amd.sharded import HipEngine
-    b = world.bit_length() - 1
-    n_local = 50000 + 17
-    cap = n_local * 2
-    eng = HipEngine(cap, 4, 0)
-    inputs = [make_keys("hash", n_local, 4, seed=300 + r) for r in range(world)]
-    split, starts = [], []
-    for r in range(world):
-        src = to_dev(inputs[r], device)
-        dst = torch.empty_like(src)
-        st = eng.split(src, dst, n_local, 32 - b, b)
-        torch.cuda.synchronize()
-        digit = inputs[r] >> np.uint32(32 - b)
-        assert np.array_equal(to_host(dst), inputs[r][np.argsort(digit, kind="stable")])
-        assert np.array_equal(st[:world], np.concatenate([[0], np.cumsum(np.bincount(digit, minlength=world))[:-1]]))
-        assert st[16] == n_local
-        split.append(dst)
-        starts.append(np.concatenate([st[:world], [n_local]]).astype(np.int64))
-    whole = []
-    for r in range(world):  # rank r receives segment r of every source, in source order
-        parts = [split[s][starts[s][r]:starts[s][r + 1]] for s in range(world)]
-        total = sum(p.numel() for p in parts)
-        keys = torch.zeros(cap, dtype=torch.int32, device=device)
-        keys[:total] = torch.cat(parts)
-        work = torch.empty_like(keys)
-        eng.sort_bits(keys, work, total, 0, 32 - b)
-        torch.cuda.synchronize()
-        shard = to_host(keys)[:total]
-        assert np.all((shard >> np.uint32(32 - b)) == r)
-        whole.append(shard.copy())
-    eng.close()
-    assert np.array_equal(np.concatenate(whole), np.sort(np.concatenate(inputs)))
-
-
 def ordered_image(keys, kind, descending):
     """numpy restatement of the order-preserving map: unsigned image whose ascending order is the wanted order."""
     bits = keys.itemsize * 8

@@ -16,24 +16,45 @@ from datasets import make_keys
 
 
 class OracleEngine:
-    """CPU stand-in for radx_amd.sharded.HipEngine, built on the oracle's pass functions."""
+    """CPU stand-in for radx_amd.sharded.HipEngine with the same contract: what each call reads,
+    writes and is allowed to clobber."""
 
-    def split(self, src, dst, n, bit, num_bits):
-        k = src[:n].numpy().view(np.uint32)
-        # one counting/partition/scattering pass on the digit (key >> bit) & (2^num_bits - 1):
-        # single-workgroup geometry, whose partitions row is the start of every digit's run
+    def __init__(self, key_bytes=4):
+        self.udt = np.uint32 if key_bytes == 4 else np.uint64
+        self.sdt = np.int32 if key_bytes == 4 else np.int64
+        self.bits = key_bytes * 8
+
+    def _u(self, t, n):
+        return t[:n].numpy().view(self.udt)
+
+    def msd_split(self, src, dst, n, log2_ranks):
+        k = self._u(src, n)
+        d = (k >> self.udt(self.bits - 4)).astype(np.uint32)
+        # bucket (rank r, sub-bucket j), d = r * S + j, goes to position p = j * G + r
+        S = 16 >> log2_ranks
+        p = (d % S) * (1 << log2_ranks) + d // S
+        # one counting/partition pass in single-workgroup geometry: its partitions row is the
+        # start of every run
         cfg = oracle.Config(bits=4, grid=1, wave=64, vec=4)
-        digit = (k >> np.uint32(bit)) & np.uint32((1 << num_bits) - 1)
-        counts = np.bincount(digit, minlength=16).astype(np.uint32).reshape(1, 16)
+        counts = np.bincount(p, minlength=16).astype(np.uint32).reshape(1, 16)
         parts = oracle.partition(cfg, counts)
-        order = np.argsort(digit, kind="stable")
-        dst[:n] = torch.from_numpy(k[order].view(np.int32).copy())
+        dst[:n] = torch.from_numpy(k[np.argsort(p, kind="stable")].view(self.sdt).copy())
         return np.concatenate([parts[0], [n]]).astype(np.uint32)
 
+    def _sorted_on(self, k, begin_bit, end_bit):
+        field = (k >> self.udt(begin_bit)) & self.udt((1 << (end_bit - begin_bit)) - 1)
+        return k[np.argsort(field, kind="stable")].view(self.sdt).copy()
+
     def sort_bits(self, keys, swap, n, begin_bit, end_bit):
-        k = keys[:n].numpy().view(np.uint32)
-        field = (k >> np.uint32(begin_bit)) & np.uint32((1 << (end_bit - begin_bit)) - 1)
-        keys[:n] = torch.from_numpy(k[np.argsort(field, kind="stable")].view(np.int32).copy())
+        res = self._sorted_on(self._u(keys, n), begin_bit, end_bit)
+        swap[:n] = -1
+        keys[:n] = torch.from_numpy(res)
+
+    def sort_bits_into(self, keys, swap, out, n, begin_bit, end_bit):
+        res = self._sorted_on(self._u(keys, n), begin_bit, end_bit)
+        keys[:n] = -1  # both ping-pong buffers are scratch
+        swap[:n] = -1
+        out[:n] = torch.from_numpy(res)
 
 
 def _free_port():
@@ -42,24 +63,28 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, n_local, dist_name, out_dir):
+def _worker(rank, world, port, n_local, dist_name, key_bytes, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from radx_amd.sharded import ShardedSorter
-        keys = make_keys(dist_name, n_local, 4, seed=100 + rank)
-        cap = n_local * world if dist_name != "hash" else ShardedSorter.suggest_capacity(n_local, 0.2)
-        kbuf = torch.zeros(cap, dtype=torch.int32)
-        kbuf[:n_local] = torch.from_numpy(keys.view(np.int32).copy())
-        work = torch.zeros(cap, dtype=torch.int32)
-        shard, total, send, recv = ShardedSorter(OracleEngine()).sort(kbuf, work, n_local)
-        got = shard.numpy().view(np.uint32).copy()
+        sdt = np.int32 if key_bytes == 4 else np.int64
+        tdt = torch.int32 if key_bytes == 4 else torch.int64
+        bits = key_bytes * 8
+        keys = make_keys(dist_name, n_local, key_bytes, seed=100 + rank)
+        cap = n_local * world + 64 if dist_name != "hash" else ShardedSorter.suggest_capacity(n_local, 0.2)
+        kbuf = torch.zeros(cap, dtype=tdt)
+        kbuf[:n_local] = torch.from_numpy(keys.view(sdt).copy())
+        work = torch.zeros(cap, dtype=tdt)
+        sharder = ShardedSorter(OracleEngine(key_bytes), key_bits=bits, exchange_when_alone=True)
+        shard, total, send, recv = sharder.sort(kbuf, work, n_local)
+        got = shard.numpy().view(keys.dtype).copy()
         assert got.size == total == int(recv.sum())
         assert int(send.sum()) == n_local
         b = world.bit_length() - 1
         if b:
-            assert np.all((got >> np.uint32(32 - b)) == rank), "shard holds a key of another rank's range"
+            assert np.all((got >> keys.dtype.type(bits - b)) == rank), "shard holds a key of another rank's range"
         assert np.all(got[1:] >= got[:-1]), "shard not sorted"
         np.save(os.path.join(out_dir, "shard%d.npy" % rank), got)
         np.save(os.path.join(out_dir, "input%d.npy" % rank), keys)
@@ -67,12 +92,42 @@ def _worker(rank, world, port, n_local, dist_name, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,dist_name", [(2, "hash"), (2, "skewed"), (4, "hash"), (2, "all_equal")])
-def test_sharded_sort_gloo(tmp_path, world, dist_name):
+@pytest.mark.parametrize("world,dist_name,key_bytes", [
+    (2, "hash", 4), (2, "skewed", 4), (4, "hash", 4), (2, "all_equal", 4), (8, "hash", 4),
+    (1, "hash", 4), (4, "hash", 8), (4, "sorted", 4)])
+def test_sharded_sort_gloo(tmp_path, world, dist_name, key_bytes):
     n_local = 20000 + 37
-    mp.spawn(_worker, args=(world, _free_port(), n_local, dist_name, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, _free_port(), n_local, dist_name, key_bytes, str(tmp_path)),
+             nprocs=world, join=True)
     shards = [np.load(tmp_path / ("shard%d.npy" % r)) for r in range(world)]
     inputs = [np.load(tmp_path / ("input%d.npy" % r)) for r in range(world)]
     whole = np.concatenate(shards)
     assert np.array_equal(whole, np.sort(np.concatenate(inputs)))
     assert oracle.checksum(whole) == oracle.checksum(np.concatenate(inputs))
+
+
+def test_plan_regions_do_not_overlap():
+    """Region j's staging range starts 16-byte aligned at or after its packed position and ends
+    before region j+1's staging range starts."""
+    from radx_amd.sharded import ShardedSorter
+
+    class Alone(ShardedSorter):
+        def __init__(self, world, rank, key_bits):
+            self.world, self.rank, self.align = world, rank, 16 // (key_bits // 8)
+
+    rng = np.random.default_rng(7)
+    for world in (1, 2, 4, 8, 16):
+        for key_bits in (32, 64):
+            for rank in (0, world - 1):
+                matrix = rng.integers(0, 50, size=(world, 16)).astype(np.int64)
+                matrix[rng.integers(0, world), :] = 0
+                recv, length, exact, staged = Alone(world, rank, key_bits).plan(matrix)
+                S = 16 // world
+                assert recv.shape == (S, world)
+                a = 16 // (key_bits // 8)
+                for j in range(S):
+                    assert staged[j] % a == 0 and staged[j] >= exact[j]
+                    assert length[j] == sum(matrix[s, j * world + rank] for s in range(world))
+                    if j + 1 < S:
+                        assert staged[j] + length[j] <= staged[j + 1]
+                        assert exact[j] + length[j] == exact[j + 1]
