@@ -31,6 +31,9 @@ def parse():
     ap.add_argument("--cpu-log2n", type=int, default=27, help="log2 of the CPU-baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other single-GPU configs")
+    ap.add_argument("--rehearse-exchange", action="store_true",
+                    help="on one GPU, run the N > 1 code path (RCCL process group of one rank, split + "
+                         "16 all-to-all-v's + per-region local passes) instead of the plain sort")
     return ap.parse_args()
 
 
@@ -131,13 +134,15 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    multi = world > 1 or args.rehearse_exchange  # the split / exchange / per-region path
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        init_process_group(dev)
+        os.environ.setdefault("MASTER_PORT", "29517")
+        init_process_group(dev, rank=rank, world_size=world)
 
     n = 1 << args.log2n
     K, W = args.steps, args.warmup
-    cap = n if world == 1 else ShardedSorter.suggest_capacity(n)
+    cap = n if not multi else ShardedSorter.suggest_capacity(n)
     batch_bytes = cap * 4
     free_b, _ = torch.cuda.mem_get_info(dev)
     budget = int(free_b * 0.75) - 3 * batch_bytes
@@ -146,7 +151,7 @@ def main():
 
     pool = [torch.empty(cap, dtype=torch.int32, device=dev) for _ in range(pool_n)]
     work = torch.empty(cap, dtype=torch.int32, device=dev)
-    stage = torch.empty(cap, dtype=torch.int32, device=dev) if world > 1 else None
+    stage = torch.empty(cap, dtype=torch.int32, device=dev) if multi else None
 
     def fill(i, step):
         radx_amd.generate_u32(pool[i], seed=(step + 1) * 7919 + rank * 104729, n=n)
@@ -154,18 +159,18 @@ def main():
     for i in range(pool_n):
         fill(i, i)
     engine = HipEngine(cap, 4, local_rank)
-    sharder = ShardedSorter(engine) if world > 1 else None
-    checks = radx_amd.checksum(pool[(K + W - 1) % pool_n], n=n) if world == 1 else None
+    sharder = ShardedSorter(engine, exchange_when_alone=True) if multi else None
+    checks = radx_amd.checksum(pool[(K + W - 1) % pool_n], n=n)  # of the last timed step's input
 
     def step(i):
-        if world == 1:
+        if not multi:
             engine.sorter.sort(pool[i], work, n=n)
             return n
         return sharder.sort(pool[i], work, n, stage)[1]
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if multi:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -188,7 +193,7 @@ def main():
             i = (W + s) % pool_n
             fill(i, W + s)
             fence()
-            if s == K - 1 and world == 1:
+            if s == K - 1:
                 checks = radx_amd.checksum(pool[i], n=n)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -200,7 +205,7 @@ def main():
     kt = engine.sorter.kernel_times()
     engine.sorter.profile(False)
 
-    if world > 1:
+    if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -209,9 +214,19 @@ def main():
     last = pool[(W + K - 1) % pool_n]
     violations = radx_amd.check_sorted(last, n=last_len)
     verified = violations == 0
-    if world == 1:
-        verified = verified and radx_amd.checksum(last, n=n) == checks
+    after = radx_amd.checksum(last, n=last_len)
+    if not multi:
+        verified = verified and after == checks
     else:
+        # the multiset of keys is preserved across the ranks: sum and mixed sum (mod 2^64) of all
+        # shards equal those of all inputs
+        def wrap(v):
+            return v - (1 << 64) if v >= (1 << 63) else v
+        sums = torch.tensor([wrap(checks[0]), wrap(checks[2]), wrap(after[0]), wrap(after[2])],
+                            dtype=torch.int64, device=dev)
+        dist.all_reduce(sums)
+        sums = sums.tolist()
+        verified = verified and sums[0] == sums[2] and sums[1] == sums[3]
         b = world.bit_length() - 1
         top = (last[:last_len] >> (32 - b)) & ((1 << b) - 1) if b else None
         if top is not None:
@@ -236,7 +251,7 @@ def main():
     copy_gbps = 3 * 2 * batch_bytes / (e0.elapsed_time(e1) / 1e3) / 1e9
 
     extras = None
-    if world == 1 and not args.no_extras:
+    if not multi and not args.no_extras:
         del pool, work
         torch.cuda.empty_cache()
         extras = other_configs(dev)
@@ -258,7 +273,7 @@ def main():
             "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {
                 "workload": "2^%d uniform (hashed) uint32 keys per GPU, full sort = 8 x 4-bit LSD passes%s"
-                            % (args.log2n, "" if world == 1 else
+                            % (args.log2n, "" if not multi else
                                ", split pass on the top digit + RCCL all-to-all-v exchange in %d "
                                "sub-buckets overlapped with the 7 local passes" % (16 // world)),
                 "keys_per_gpu": n, "total_keys": n * world, "key_bytes": 4, "passes": 8,
@@ -285,7 +300,7 @@ def main():
         print(json.dumps(out), flush=True)
 
     engine.close()
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -37,12 +37,11 @@ SPLIT_BITS = 4  # the split pass always takes one whole 4-bit digit
 
 def init_process_group(device, **kwargs):
     """torch.distributed over RCCL for one rank per GPU, rank / world size / rendezvous from the
-    environment torch.distributed.run sets (or from kwargs).  RCCL's stream gets high priority so
-    that an exchange in flight keeps its workgroups scheduled while local sort passes, which fill
-    every CU, run beside it."""
+    environment torch.distributed.run sets (or from kwargs).  RCCL's stream is left at normal
+    priority: on ROCm 7.0 / RCCL 2.26 a process group created with is_high_priority_stream=True
+    after the process had already run kernels never completed its first all-to-all."""
     import torch.distributed as dist
-    options = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-    dist.init_process_group("nccl", device_id=device, pg_options=options, **kwargs)
+    dist.init_process_group("nccl", device_id=device, **kwargs)
 
 
 class HipEngine:

@@ -144,7 +144,8 @@ class ReplayDist:
         j, G = self.calls, self.world
         self.calls += 1
         mine = self.starts[self.rank]
-        assert inp.data_ptr() == self.split_bufs[self.rank][mine[j * G]:].data_ptr()
+        if inp.numel():
+            assert inp.data_ptr() == self.split_bufs[self.rank][mine[j * G]:].data_ptr()
         assert inp.numel() == mine[(j + 1) * G] - mine[j * G] == sum(input_split_sizes)
         assert input_split_sizes == np.diff(mine[j * G:(j + 1) * G + 1]).tolist()
         assert out.numel() == sum(output_split_sizes)
