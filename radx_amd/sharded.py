@@ -94,6 +94,7 @@ class ShardedSorter:
         # the whole pipeline through the real backend on a single GPU
         self.exchange_when_alone = exchange_when_alone
         self._stage = None
+        self._side = None  # stream the local passes run on (device tensors only)
 
     @staticmethod
     def suggest_capacity(n_local, slack=0.05):
@@ -153,10 +154,24 @@ class ShardedSorter:
 
         # 4. local LSD passes per region as it lands; the last pass packs it into keys[exact[j]:]
         low_bits = self.key_bits - SPLIT_BITS
-        for j in range(S):
-            pending[j].wait()
-            c, m = int(staged[j]), int(length[j])
-            if m:
-                self.engine.sort_bits_into(stage[c:], keys[c:], keys[int(exact[j]):], m, 0, low_bits)
+
+        def local_passes():
+            for j in range(S):
+                pending[j].wait()  # a dependency of the current stream on exchange j, not a host wait
+                c, m = int(staged[j]), int(length[j])
+                if m:
+                    self.engine.sort_bits_into(stage[c:], keys[c:], keys[int(exact[j]):], m, 0, low_bits)
+
+        if keys.is_cuda:
+            # The local passes go to a stream of their own: streams share hardware queues, and
+            # kernels of two streams on one queue run in submission order — behind all S exchanges.
+            if self._side is None or self._side.device != keys.device:
+                self._side = torch.cuda.Stream(keys.device)
+            caller = torch.cuda.current_stream(keys.device)
+            with torch.cuda.stream(self._side):
+                local_passes()
+            caller.wait_stream(self._side)
+        else:
+            local_passes()
         send = runs.reshape(S, G).sum(axis=0)
         return keys[:total], total, send, recv.sum(axis=0)
