@@ -227,12 +227,15 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
 // Kernel 1: every scan workgroup takes 256 consecutive table rows (one per thread) and scans each
 // of the 16 radix columns across them, leaving the column totals (and zeroes the same rows of the
 // table the following scatter pass accumulates the next pass's counts in).  Kernel 2 (one workgroup) scans
-// those totals in (radix, scan-workgroup) order.  The scatter kernel adds the two parts.
+// those totals in (radix, scan-workgroup) order.  The scatter kernel adds the two parts.  When
+// the whole table fits one scan workgroup (at most 256 tiles) kernel 1 scans its 16 totals itself
+// and kernel 2 is not launched.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void scan_rows_kernel(const uint32_t* __restrict__ counts,
                                                             uint32_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ group_sums,
-                                                            uint32_t num_tiles, uint32_t* __restrict__ clear) {
+                                                            uint32_t num_tiles, uint32_t* __restrict__ clear,
+                                                            uint32_t n, uint32_t* __restrict__ digit_starts) {
     __shared__ uint32_t wave_tot[kBlock / 64][kRadices];
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const uint32_t row = blockIdx.x * kScanBlocks + tid;
@@ -275,11 +278,19 @@ __global__ __launch_bounds__(kBlock) void scan_rows_kernel(const uint32_t* __res
             for (int q = 0; q < 4; ++q) z[q] = make_uint4(0u, 0u, 0u, 0u);
         }
     }
-    if (tid < static_cast<uint32_t>(kRadices)) {
+    if (wave == 0u) {
         uint32_t all = 0;
+        if (tid < static_cast<uint32_t>(kRadices)) {
 #pragma unroll
-        for (int w = 0; w < kBlock / 64; ++w) all += wave_tot[w][tid];
-        group_sums[static_cast<size_t>(tid) * gridDim.x + blockIdx.x] = all;
+            for (int w = 0; w < kBlock / 64; ++w) all += wave_tot[w][tid];
+        }
+        if (gridDim.x == 1u) {  // the only scan workgroup: its totals are the digit totals
+            const uint32_t start = wave_inclusive_scan(all) - all;
+            if (tid < static_cast<uint32_t>(kRadices)) { group_sums[tid] = start; digit_starts[tid] = start; }
+            if (tid == 0u) digit_starts[kRadices] = n;
+        } else if (tid < static_cast<uint32_t>(kRadices)) {
+            group_sums[static_cast<size_t>(tid) * gridDim.x + blockIdx.x] = all;
+        }
     }
 }
 
@@ -821,9 +832,11 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
     {
         LaunchTimer t(s, 1, stream);
         hipLaunchKernelGGL(scan_rows_kernel, dim3(g.num_groups), dim3(kBlock), 0, stream, counts, s->offsets,
-                           s->group_sums, g.num_tiles, a.fuse_next ? next_counts : static_cast<uint32_t*>(nullptr));
-        hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, stream, s->group_sums, g.num_groups,
+                           s->group_sums, g.num_tiles, a.fuse_next ? next_counts : static_cast<uint32_t*>(nullptr),
                            a.n, s->digit_starts);
+        if (g.num_groups > 1)
+            hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, stream, s->group_sums, g.num_groups,
+                               a.n, s->digit_starts);
     }
     {
         LaunchTimer t(s, 2, stream);
