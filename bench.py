@@ -291,6 +291,11 @@ def main():
                 "launches": scatter_launches, "avg_launch_ms": round(avg_ms, 4),
                 "algorithmic_bytes_per_launch": alg_bytes},
         }
+        if multi:
+            # xGMI traffic of one step, reported beside the HBM figures (never part of them)
+            out["exchange"] = {"bytes_sent_per_gpu": round(4.0 * n * (world - 1) / world),
+                               "all_to_all_calls_per_step": 16 // world, "backend": "nccl (RCCL)",
+                               "overlapped_with_local_passes": True}
         if extras is not None:
             out["other_configs"] = extras
         if world == 1 and not args.no_cpu:
