@@ -236,3 +236,40 @@ def test_sharded_sorter_over_rccl_world_of_one(device):
         eng.close()
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kind,descending", [("signed", False), ("float", True), ("unsigned", True)])
+def test_sharded_sorter_follows_key_order(device, kind, descending):
+    """With a key order set on the engine's sorter the split digit, the shard boundaries and the
+    local passes all work on the order-preserving image: rank r holds the r-th quarter of that
+    order and the shards concatenate to the stable sort by image."""
+    import torch
+    from radx_amd.sharded import HipEngine, ShardedSorter
+    from test_gpu_sort import ordered_image
+    world, n_local = 4, 30000 + 5
+    cap = ShardedSorter.suggest_capacity(n_local, 0.3)
+    eng = HipEngine(cap, 4, 0)
+    eng.sorter.set_key_order(kind, descending)
+    inputs = [make_keys("uniform", n_local, 4, seed=400 + r) for r in range(world)]
+    split_bufs, starts = [], []
+    for r in range(world):
+        src = to_dev(inputs[r], device)
+        dst = torch.empty_like(src)
+        starts.append(eng.msd_split(src, dst, n_local, 2).astype(np.int64))
+        split_bufs.append(dst)
+    whole = []
+    for r in range(world):
+        keys = torch.zeros(cap, dtype=torch.int32, device=device)
+        keys[:n_local] = to_dev(inputs[r], device)
+        work = torch.zeros(cap, dtype=torch.int32, device=device)
+        split_bufs[r] = work
+        sharder = ShardedSorter(eng, dist=ReplayDist(r, world, split_bufs, starts))
+        shard, total, _, _ = sharder.sort(keys, work, n_local)
+        torch.cuda.synchronize()
+        got = to_host(shard).copy()
+        assert np.all((ordered_image(got, kind, descending) >> np.uint32(30)) == r)
+        whole.append(got)
+    eng.close()
+    everything = np.concatenate(inputs)
+    expect = everything[np.argsort(ordered_image(everything, kind, descending), kind="stable")]
+    assert np.array_equal(np.concatenate(whole), expect)
