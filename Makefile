@@ -35,11 +35,13 @@ resources:
 	    grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" | grep -v "^$$" || true
 
 # development micro-benchmark: HBM copy ceilings by access width and launch shape
-micro: tools/micro/copy_bench
+micro: tools/micro/copy_bench tools/micro/rocprim_sort_bench
+tools/micro/rocprim_sort_bench: tools/micro/rocprim_sort_bench.hip
+	$(HIPCC) -O3 -w --offload-arch=$(ARCH) -o $@ $<
 tools/micro/copy_bench: tools/micro/copy_bench.hip
 	$(HIPCC) -O3 -w --offload-arch=$(ARCH) -o $@ $<
 
 clean:
-	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) tools/micro/copy_bench
+	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) tools/micro/copy_bench tools/micro/rocprim_sort_bench
 
 .PHONY: all clean resources micro
