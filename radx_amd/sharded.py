@@ -131,17 +131,23 @@ class ShardedSorter:
         starts = self.engine.msd_split(keys, work, n_local, b).astype(np.int64)
         runs = np.diff(starts)  # 16 run lengths; starts[16] == n_local
 
-        # 2. every rank learns the whole [source][16] matrix of run lengths
-        mine = torch.tensor(runs, dtype=torch.int64, device=keys.device)
-        matrix = torch.empty(G * 16, dtype=torch.int64, device=keys.device)
-        self.dist.all_gather_into_tensor(matrix, mine, group=self.group)
-        matrix = matrix.cpu().numpy().reshape(G, 16)
+        # 2. every rank learns the whole [source][16] matrix of run lengths, and every rank's capacity
+        capacity = min(keys.numel(), stage.numel())
+        mine = torch.tensor(np.append(runs, capacity), dtype=torch.int64, device=keys.device)
+        gathered = torch.empty(G * 17, dtype=torch.int64, device=keys.device)
+        self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
+        gathered = gathered.cpu().numpy().reshape(G, 17)
+        matrix, capacities = gathered[:, :16], gathered[:, 16]
+        # Every rank checks every rank's shard against that rank's buffers, so that all of them
+        # raise together instead of one leaving the others waiting in the exchange.
+        shard_lens = matrix.reshape(G, S, G).sum(axis=(0, 1))       # [destination rank]
+        padded = shard_lens + (S - 1) * (self.align - 1)            # worst-case staging padding
+        if np.any(padded > capacities):
+            r = int(np.argmax(padded - capacities))
+            raise RuntimeError("rank %d receives %d keys (up to %d with alignment padding) but its buffers hold %d: "
+                               "allocate more slack" % (r, shard_lens[r], padded[r], capacities[r]))
         recv, length, exact, staged = self.plan(matrix)
         total = int(length.sum())
-        need = int(staged[-1] + length[-1])
-        if need > keys.numel() or need > stage.numel():
-            raise RuntimeError("rank %d receives %d keys (%d with alignment padding) but its buffers hold %d: "
-                               "allocate more slack" % (self.rank, total, need, min(keys.numel(), stage.numel())))
 
         # 3. the exchange, one all-to-all-v per sub-bucket, all in flight at once
         pending = []

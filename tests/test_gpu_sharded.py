@@ -137,8 +137,10 @@ class ReplayDist:
     def all_gather_into_tensor(self, out, mine, group=None):
         import torch
         runs = np.stack([np.diff(st) for st in self.starts])
-        assert np.array_equal(mine.cpu().numpy(), runs[self.rank])
-        out.copy_(torch.from_numpy(runs.reshape(-1)).to(out.device))
+        mine = mine.cpu().numpy()
+        assert np.array_equal(mine[:16], runs[self.rank])
+        rows = np.concatenate([runs, np.full((self.world, 1), mine[16])], axis=1)  # same capacity everywhere
+        out.copy_(torch.from_numpy(rows.reshape(-1)).to(out.device))
 
     def all_to_all_single(self, out, inp, output_split_sizes, input_split_sizes, group=None, async_op=False):
         j, G = self.calls, self.world

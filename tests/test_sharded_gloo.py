@@ -106,6 +106,38 @@ def test_sharded_sort_gloo(tmp_path, world, dist_name, key_bytes):
     assert oracle.checksum(whole) == oracle.checksum(np.concatenate(inputs))
 
 
+def _overflow_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from radx_amd.sharded import ShardedSorter
+        n_local = 5000
+        keys = np.full(n_local, 0x10000000 + rank, dtype=np.uint32)  # every key belongs to rank 0
+        cap = n_local + 100                                          # rank 0 would need 2 * n_local
+        kbuf = torch.zeros(cap, dtype=torch.int32)
+        kbuf[:n_local] = torch.from_numpy(keys.view(np.int32).copy())
+        work = torch.zeros(cap, dtype=torch.int32)
+        try:
+            ShardedSorter(OracleEngine(4)).sort(kbuf, work, n_local)
+            outcome = "sorted"
+        except RuntimeError as e:
+            outcome = str(e)
+        with open(os.path.join(out_dir, "outcome%d.txt" % rank), "w") as f:
+            f.write(outcome)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_shard_overflow_is_raised_on_every_rank(tmp_path):
+    """A shard that does not fit its rank's buffers is an error on ALL ranks, before the exchange
+    starts — nobody is left waiting in a collective."""
+    mp.spawn(_overflow_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        text = (tmp_path / ("outcome%d.txt" % r)).read_text()
+        assert "rank 0 receives 10000 keys" in text and "allocate more slack" in text
+
+
 def test_plan_regions_do_not_overlap():
     """Region j's staging range starts 16-byte aligned at or after its packed position and ends
     before region j+1's staging range starts."""
