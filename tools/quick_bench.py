@@ -24,6 +24,7 @@ s = radx_amd.Sorter(n, kb, vb)
 s.tune(bool(fuse))
 s.profile(True)
 passes = kb * 2
+totals, scatters = [], []
 for it in range(iters):
     if kb == 4:
         radx_amd.generate_u32(k, seed=it + 1)
@@ -38,8 +39,16 @@ for it in range(iters):
     ms = e0.elapsed_time(e1)
     t = s.kernel_times()
     bytes_alg = passes * n * 2 * (kb + vb)
+    if it:
+        totals.append(ms)
+        scatters.append(t["scatter"][0] / max(1, t["scatter"][1]))
     print("n=2^%d iter %d: %.3f ms  %.2f Gkeys/s  alg %.0f GB/s (%.1f%% of 8 TB/s) | hist %.3f scan %.3f scatter %.3f ms/launch"
           % (log2n, it, ms, n / ms / 1e6, bytes_alg / ms / 1e6, bytes_alg / ms / 1e6 / 80.0,
              t["hist"][0] / max(1, t["hist"][1]), t["scan"][0] / max(1, t["scan"][1]),
              t["scatter"][0] / max(1, t["scatter"][1])), flush=True)
+if totals:
+    totals.sort()
+    scatters.sort()
+    print("median of %d (first skipped): sort %.3f ms, scatter %.4f ms/launch; best sort %.3f ms"
+          % (len(totals), totals[len(totals) // 2], scatters[len(scatters) // 2], totals[0]))
 print("violations:", radx_amd.check_sorted(k, v))
