@@ -11,8 +11,9 @@ LIB      := radx_amd/lib/libradx_hip.so
 ORACLE   := oracle/libradx_oracle.so
 CPUSORT  := oracle/libradx_cpusort.so
 HARNESS  := harness/sort_test
+SHARDED  := harness/sharded_test
 
-all: $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS)
+all: $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) $(SHARDED)
 
 $(LIB): radx_amd/csrc/radx_hip.hip include/radx_hip.h
 	@mkdir -p radx_amd/lib
@@ -30,6 +31,14 @@ $(HARNESS): harness/sort_test.cpp $(LIB) $(wildcard include/radx/*.hpp) include/
 	    -Lradx_amd/lib -lradx_hip -L/opt/rocm/lib -lamdhip64 \
 	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,/opt/rocm/lib
 
+# the multi-GPU harness links RCCL; it prefers the RCCL that ships with PyTorch when present at
+# run time only through LD_LIBRARY_PATH — the build uses ROCm's own
+$(SHARDED): harness/sharded_test.cpp $(LIB) $(wildcard include/radx/*.hpp) include/radx_hip.h
+	$(CXX) -O2 -std=c++17 -pthread -Wall -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
+	    -o $@ harness/sharded_test.cpp \
+	    -Lradx_amd/lib -lradx_hip -L/opt/rocm/lib -lamdhip64 -lrccl \
+	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,/opt/rocm/lib
+
 resources:
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null radx_amd/csrc/radx_hip.hip 2>&1 | \
 	    grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" | grep -v "^$$" || true
@@ -42,6 +51,6 @@ tools/micro/copy_bench: tools/micro/copy_bench.hip
 	$(HIPCC) -O3 -w --offload-arch=$(ARCH) -o $@ $<
 
 clean:
-	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) tools/micro/copy_bench tools/micro/rocprim_sort_bench
+	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) $(SHARDED) tools/micro/copy_bench tools/micro/rocprim_sort_bench
 
 .PHONY: all clean resources micro

@@ -1,0 +1,176 @@
+// radx_sharded.hpp — a sort spread over the GPUs of one node, for C++ hosts: the C ABI of
+// radx_hip.h plus RCCL point-to-point calls.  No counterpart in the reference, which is
+// single-device; it is the exchange step a multi-GPU radix sort needs, placed between the first
+// 4-bit pass and the other passes of the same sort (8 passes over every key for uint32, as on one
+// GPU).  radx_amd/sharded.py is the same pipeline over torch.distributed.
+//
+// One ShardedSort per GPU (one host thread or process each), all with communicators of one
+// RCCL clique.  With G ranks and S = 16 / G sub-buckets per rank:
+//   1. split     radx_hip_msd_split: stable partition on the top digit d = (rank r, sub-bucket j),
+//                runs written in (j, r) order, so every sub-bucket's send buffer is contiguous;
+//   2. counts    ncclAllGather of the 16 run lengths and the buffer capacity of every rank;
+//   3. exchange  per sub-bucket j one grouped ncclSend/ncclRecv (an all-to-all-v) on a stream of
+//                its own, landing grouped by source in region j of `stage`;
+//   4. passes    region j is sorted on the low bits as soon as exchange j has landed
+//                (radx_hip_sort_bits_into on a third stream) while exchanges j+1.. are in flight;
+//                its last pass stores to the region's final place in `keys`.
+// After sort(), keys[0, shard) on rank r is the ascending run of all keys whose top log2(G) bits
+// equal r.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "radx_core.hpp"
+
+namespace radx {
+
+    class ShardedSort {
+    public:
+        // capacity: elements each of keys / work / stage holds (>= n_local and >= the shard this
+        // rank receives plus a few elements of alignment padding).
+        ShardedSort(int device, int rank, int world, ncclComm_t comm, std::size_t capacity, int keyBytes = 4)
+            : device_(device), rank_(rank), world_(world), comm_(comm), capacity_(capacity), keyBytes_(keyBytes) {
+            if (world < 1 || world > 16 || (world & (world - 1)))
+                throw Error(static_cast<int>(hipErrorInvalidValue), "ShardedSort: world size must be a power of two <= 16");
+            while ((1 << log2World_) < world) ++log2World_;
+            check_hip(hipSetDevice(device_), "hipSetDevice");
+            check_abi(radx_hip_create(device_, capacity_, keyBytes_, 0, &sorter_));
+            check_hip(hipStreamCreateWithFlags(&exchangeStream_, hipStreamNonBlocking), "hipStreamCreate");
+            check_hip(hipStreamCreateWithFlags(&passStream_, hipStreamNonBlocking), "hipStreamCreate");
+            check_hip(hipEventCreateWithFlags(&splitDone_, hipEventDisableTiming), "hipEventCreate");
+            check_hip(hipEventCreateWithFlags(&passesDone_, hipEventDisableTiming), "hipEventCreate");
+            for (auto& e : landed_) check_hip(hipEventCreateWithFlags(&e, hipEventDisableTiming), "hipEventCreate");
+            check_hip(hipMalloc(reinterpret_cast<void**>(&gathered_), sizeof(int64_t) * kRow * (world_ + 1)), "hipMalloc");
+        }
+        ShardedSort(const ShardedSort&) = delete;
+        ShardedSort& operator=(const ShardedSort&) = delete;
+        ~ShardedSort() {
+            (void)hipSetDevice(device_);
+            (void)hipFree(gathered_);
+            for (auto& e : landed_) (void)hipEventDestroy(e);
+            (void)hipEventDestroy(splitDone_);
+            (void)hipEventDestroy(passesDone_);
+            (void)hipStreamDestroy(exchangeStream_);
+            (void)hipStreamDestroy(passStream_);
+            (void)radx_hip_destroy(sorter_);
+        }
+
+        radx_hip_sorter* handle() const { return sorter_; }
+
+        // Enqueues the whole sort; `stream` carries the split and, at the end, waits for the local
+        // passes, so work enqueued on it afterwards sees the shard.  Blocks the host twice (run
+        // lengths, gathered matrix).  Returns the shard length.  Every rank throws the same Error
+        // when any rank's shard would not fit its buffers.
+        std::size_t sort(void* keys, void* work, void* stage, std::size_t nLocal, hipStream_t stream) {
+            const int G = world_, S = 16 / G, keyBits = keyBytes_ * 8;
+            const std::size_t align = 16 / keyBytes_;
+            if (nLocal > capacity_) throw Error(static_cast<int>(hipErrorInvalidValue), "ShardedSort: nLocal exceeds capacity");
+            check_hip(hipSetDevice(device_), "hipSetDevice");
+
+            // 1. split: keys -> work
+            uint32_t starts32[17] = {0};
+            if (nLocal) {
+                check_abi(radx_hip_msd_split(sorter_, keys, work, nullptr, nullptr, nLocal, log2World_, stream));
+                check_abi(radx_hip_digit_starts(sorter_, starts32, stream));
+            }
+            int64_t starts[17];
+            for (int p = 0; p <= 16; ++p) starts[p] = nLocal ? starts32[p] : 0;
+
+            // 2. every rank learns every rank's 16 run lengths and capacity
+            int64_t mine[kRow];
+            for (int p = 0; p < 16; ++p) mine[p] = starts[p + 1] - starts[p];
+            mine[16] = static_cast<int64_t>(capacity_);
+            int64_t* dMine = gathered_ + static_cast<std::size_t>(world_) * kRow;
+            check_hip(hipMemcpyAsync(dMine, mine, sizeof(mine), hipMemcpyHostToDevice, stream), "hipMemcpyAsync");
+            check_nccl(ncclAllGather(dMine, gathered_, kRow, ncclInt64, comm_, stream), "ncclAllGather");
+            std::vector<int64_t> all(static_cast<std::size_t>(world_) * kRow);
+            check_hip(hipMemcpyAsync(all.data(), gathered_, all.size() * sizeof(int64_t), hipMemcpyDeviceToHost, stream),
+                      "hipMemcpyAsync");
+            check_hip(hipStreamSynchronize(stream), "hipStreamSynchronize");
+            auto runOf = [&](int src, int j, int dst) { return all[static_cast<std::size_t>(src) * kRow + j * G + dst]; };
+
+            // the same check on every rank, so all of them throw together
+            for (int r = 0; r < G; ++r) {
+                int64_t shard = 0;
+                for (int src = 0; src < G; ++src)
+                    for (int j = 0; j < S; ++j) shard += runOf(src, j, r);
+                const int64_t padded = shard + static_cast<int64_t>((S - 1) * (align - 1));
+                const int64_t cap = all[static_cast<std::size_t>(r) * kRow + 16];
+                if (padded > cap)
+                    throw Error(static_cast<int>(hipErrorOutOfMemory),
+                                "ShardedSort: rank " + std::to_string(r) + " receives " + std::to_string(shard) +
+                                    " keys but its buffers hold " + std::to_string(cap));
+            }
+
+            // region j: length, exact start in the packed shard, 16-byte aligned start in `stage`
+            int64_t length[16], exact[16], staged[16];
+            int64_t total = 0, cursor = 0;
+            for (int j = 0; j < S; ++j) {
+                length[j] = 0;
+                for (int src = 0; src < G; ++src) length[j] += runOf(src, j, rank_);
+                exact[j] = total;
+                staged[j] = (cursor + static_cast<int64_t>(align) - 1) / static_cast<int64_t>(align) * static_cast<int64_t>(align);
+                total += length[j];
+                cursor = staged[j] + length[j];
+            }
+
+            // 3. the exchange, one grouped send/recv per sub-bucket, on its own stream
+            const ncclDataType_t keyType = keyBytes_ == 4 ? ncclUint32 : ncclUint64;
+            char* workBytes = static_cast<char*>(work);
+            char* stageBytes = static_cast<char*>(stage);
+            char* keysBytes = static_cast<char*>(keys);
+            check_hip(hipEventRecord(splitDone_, stream), "hipEventRecord");
+            check_hip(hipStreamWaitEvent(exchangeStream_, splitDone_, 0), "hipStreamWaitEvent");
+            for (int j = 0; j < S; ++j) {
+                check_nccl(ncclGroupStart(), "ncclGroupStart");
+                int64_t at = staged[j];
+                for (int peer = 0; peer < G; ++peer) {
+                    const int64_t sendCount = mine[j * G + peer], recvCount = runOf(peer, j, rank_);
+                    if (sendCount)
+                        check_nccl(ncclSend(workBytes + starts[j * G + peer] * keyBytes_, static_cast<std::size_t>(sendCount),
+                                            keyType, peer, comm_, exchangeStream_), "ncclSend");
+                    if (recvCount)
+                        check_nccl(ncclRecv(stageBytes + at * keyBytes_, static_cast<std::size_t>(recvCount), keyType, peer,
+                                            comm_, exchangeStream_), "ncclRecv");
+                    at += recvCount;
+                }
+                check_nccl(ncclGroupEnd(), "ncclGroupEnd");
+                check_hip(hipEventRecord(landed_[j], exchangeStream_), "hipEventRecord");
+            }
+
+            // 4. local passes per region as it lands; the last pass packs it into keys[exact[j]:]
+            for (int j = 0; j < S; ++j) {
+                check_hip(hipStreamWaitEvent(passStream_, landed_[j], 0), "hipStreamWaitEvent");
+                if (length[j])
+                    check_abi(radx_hip_sort_bits_into(sorter_, stageBytes + staged[j] * keyBytes_, keysBytes + staged[j] * keyBytes_,
+                                                      nullptr, nullptr, static_cast<uint64_t>(length[j]), 0, keyBits - 4,
+                                                      keysBytes + exact[j] * keyBytes_, nullptr, passStream_));
+            }
+            check_hip(hipEventRecord(passesDone_, passStream_), "hipEventRecord");
+            check_hip(hipStreamWaitEvent(stream, passesDone_, 0), "hipStreamWaitEvent");
+            return static_cast<std::size_t>(total);
+        }
+
+    private:
+        static constexpr int kRow = 17;  // 16 run lengths + capacity
+
+        static void check_nccl(ncclResult_t r, const char* what) {
+            if (r != ncclSuccess) throw Error(static_cast<int>(hipErrorUnknown), std::string(what) + ": " + ncclGetErrorString(r));
+        }
+
+        int device_, rank_, world_, log2World_ = 0;
+        ncclComm_t comm_;
+        std::size_t capacity_;
+        int keyBytes_;
+        radx_hip_sorter* sorter_ = nullptr;
+        hipStream_t exchangeStream_ = nullptr, passStream_ = nullptr;
+        hipEvent_t splitDone_ = nullptr, passesDone_ = nullptr, landed_[16] = {};
+        int64_t* gathered_ = nullptr;  // device: world rows gathered + this rank's row
+    };
+
+}  // namespace radx

@@ -38,3 +38,26 @@ def test_harness_staged_pipeline(device):
     line = run("--log2n", "22", "--dist", "uniform", "--batches", "5")
     assert line["pass"] is True and line["batches"] == 5
     assert line["overlapped_ms"] > 0 and line["serialised_ms"] > 0
+
+
+SHARDED = os.path.join(ROOT, "harness", "sharded_test")
+
+
+def run_sharded(*args):
+    out = subprocess.run([SHARDED] + list(args), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Sorting Finished: PASS" in out.stdout
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("log2n", ["16", "22"])
+def test_sharded_harness_one_gpu_through_rccl(device, log2n):
+    """radx::ShardedSort from a C++ host: split, 16 grouped RCCL send/recv exchanges (to itself),
+    per-region passes on their own stream; checked for full equality with std::sort."""
+    line = run_sharded("--gpus", "1", "--log2n", log2n, "--iters", "2", "--force-exchange")
+    assert line["pass"] is True and line["exchange"] is True and line["full_equality_checked"] is True
+
+
+def test_sharded_harness_plain_path(device):
+    line = run_sharded("--gpus", "1", "--log2n", "20", "--iters", "1")
+    assert line["pass"] is True and line["exchange"] is False
