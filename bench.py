@@ -159,7 +159,7 @@ def main():
     for i in range(pool_n):
         fill(i, i)
     engine = HipEngine(cap, 4, local_rank)
-    sharder = ShardedSorter(engine, exchange_when_alone=True) if multi else None
+    sharder = ShardedSorter(engine, exchange_when_alone=True, profile=True) if multi else None
     checks = radx_amd.checksum(pool[(K + W - 1) % pool_n], n=n)  # of the last timed step's input
 
     def step(i):
@@ -204,6 +204,7 @@ def main():
         timing = "per-step HIP events (batch pool of %d regenerated between steps)" % pool_n
     kt = engine.sorter.kernel_times()
     engine.sorter.profile(False)
+    timeline = sharder.timeline() if multi else None
 
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -295,7 +296,8 @@ def main():
             # xGMI traffic of one step, reported beside the HBM figures (never part of them)
             out["exchange"] = {"bytes_sent_per_gpu": round(4.0 * n * (world - 1) / world),
                                "all_to_all_calls_per_step": 16 // world, "backend": "nccl (RCCL)",
-                               "overlapped_with_local_passes": True}
+                               "overlapped_with_local_passes": True,
+                               "last_step_timeline_ms_rank0": timeline}
         if extras is not None:
             out["other_configs"] = extras
         if world == 1 and not args.no_cpu:

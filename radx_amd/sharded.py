@@ -77,7 +77,7 @@ class ShardedSorter:
     `stage` is allocated on first use when not given.  The shard is returned as a view of `keys`.
     """
 
-    def __init__(self, engine, group=None, key_bits=32, exchange_when_alone=False, dist=None):
+    def __init__(self, engine, group=None, key_bits=32, exchange_when_alone=False, dist=None, profile=False):
         if dist is None:  # anything with torch.distributed's collectives can be injected instead
             import torch.distributed as dist
         self.dist = dist
@@ -95,6 +95,10 @@ class ShardedSorter:
         self.exchange_when_alone = exchange_when_alone
         self._stage = None
         self._side = None  # stream the local passes run on (device tensors only)
+        # profile: bracket the phases of every sort with events (device tensors only); timeline()
+        # reports the last sort's
+        self.profile = profile
+        self._marks = None
 
     @staticmethod
     def suggest_capacity(n_local, slack=0.05):
@@ -127,8 +131,16 @@ class ShardedSorter:
             stage = self._stage
         S = 16 // G
 
+        marks = None
+        if self.profile and keys.is_cuda:
+            marks = {"start": torch.cuda.Event(enable_timing=True), "split": torch.cuda.Event(enable_timing=True),
+                     "landed": [], "sorted": []}
+            marks["start"].record()
+
         # 1. stable split on the top digit: keys -> work, runs in (sub-bucket, destination rank) order
         starts = self.engine.msd_split(keys, work, n_local, b).astype(np.int64)
+        if marks:
+            marks["split"].record()
         runs = np.diff(starts)  # 16 run lengths; starts[16] == n_local
 
         # 2. every rank learns the whole [source][16] matrix of run lengths, and every rank's capacity
@@ -164,9 +176,15 @@ class ShardedSorter:
         def local_passes():
             for j in range(S):
                 pending[j].wait()  # a dependency of the current stream on exchange j, not a host wait
+                if marks:
+                    marks["landed"].append(torch.cuda.Event(enable_timing=True))
+                    marks["landed"][-1].record()
                 c, m = int(staged[j]), int(length[j])
                 if m:
                     self.engine.sort_bits_into(stage[c:], keys[c:], keys[int(exact[j]):], m, 0, low_bits)
+                if marks:
+                    marks["sorted"].append(torch.cuda.Event(enable_timing=True))
+                    marks["sorted"][-1].record()
 
         if keys.is_cuda:
             # The local passes go to a stream of their own: streams share hardware queues, and
@@ -179,5 +197,18 @@ class ShardedSorter:
             caller.wait_stream(self._side)
         else:
             local_passes()
+        self._marks = marks
         send = runs.reshape(S, G).sum(axis=0)
         return keys[:total], total, send, recv.sum(axis=0)
+
+    def timeline(self):
+        """Milliseconds from the start of the last profiled sort to: the split done, every
+        exchange landed (as seen by the stream of the local passes: exchange j done and region
+        j-1 sorted) and every region sorted.  Synchronises.  None when nothing was profiled."""
+        m = self._marks
+        if not m:
+            return None
+        m["sorted"][-1].synchronize()
+        since = lambda e: round(m["start"].elapsed_time(e), 3)
+        return {"split_done": since(m["split"]), "exchange_landed": [since(e) for e in m["landed"]],
+                "region_sorted": [since(e) for e in m["sorted"]]}
