@@ -1,5 +1,5 @@
-"""bench.py at a small size on the GPU: the one-GPU line and the N > 1 code path rehearsed over
-RCCL with a single rank.  Checks the JSON contract, not the speed."""
+"""bench.py at a small size on the GPU: the one-GPU line (the N > 1 code path, rehearsed over RCCL
+with a single rank, is in test_gpu_zz_rccl.py).  Checks the JSON contract, not the speed."""
 import json
 import os
 import socket
@@ -47,14 +47,3 @@ def test_bench_single_gpu_line(device):
     cpu = line["cpu_baseline"]
     assert cpu["kind"] == "port" and cpu["cores"] >= 1 and cpu["value"] > 0 and cpu["unit"] == "Gkeys/s"
     assert line["roofline"]["launches"] == 3 * 8
-
-
-def test_bench_exchange_path_rehearsed(device):
-    line = run_bench("--log2n", "22", "--steps", "2", "--warmup", "1", "--no-cpu", "--rehearse-exchange")
-    check_contract(line, 2, 1)
-    assert line["exchange"]["all_to_all_calls_per_step"] == 16
-    timeline = line["exchange"]["last_step_timeline_ms_rank0"]
-    assert len(timeline["exchange_landed"]) == len(timeline["region_sorted"]) == 16
-    assert 0 < timeline["split_done"] < timeline["region_sorted"][-1]
-    # one split pass over all keys + 7 passes over each of the 16 regions, per step
-    assert line["roofline"]["launches"] == 2 * (1 + 7 * 16)

@@ -50,14 +50,6 @@ def run_sharded(*args):
     return json.loads(out.stdout.strip().splitlines()[-1])
 
 
-@pytest.mark.parametrize("log2n", ["16", "22"])
-def test_sharded_harness_one_gpu_through_rccl(device, log2n):
-    """radx::ShardedSort from a C++ host: split, 16 grouped RCCL send/recv exchanges (to itself),
-    per-region passes on their own stream; checked for full equality with std::sort."""
-    line = run_sharded("--gpus", "1", "--log2n", log2n, "--iters", "2", "--force-exchange")
-    assert line["pass"] is True and line["exchange"] is True and line["full_equality_checked"] is True
-
-
 def test_sharded_harness_plain_path(device):
     line = run_sharded("--gpus", "1", "--log2n", "20", "--iters", "1")
     assert line["pass"] is True and line["exchange"] is False

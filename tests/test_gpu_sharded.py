@@ -1,9 +1,6 @@
 """GPU tests of the multi-GPU path's building blocks and of ShardedSorter itself on one GPU:
-the split pass, the pack-into-place local sort, the whole pipeline with the exchange replayed
-by copies for every rank of a 2..16-rank world, and the real RCCL backend in a world of one."""
-import os
-import socket
-
+the split pass, the pack-into-place local sort, and the whole pipeline with the exchange replayed
+by copies for every rank of a 1..16-rank world (the real RCCL backend: test_gpu_zz_rccl.py)."""
 import numpy as np
 import pytest
 
@@ -200,44 +197,6 @@ def test_sharded_sorter_every_rank_replayed(device, world, key_bytes, dist_name)
         whole.append(got)
     eng.close()
     assert np.array_equal(np.concatenate(whole), np.sort(np.concatenate(inputs)))
-
-
-def test_sharded_sorter_over_rccl_world_of_one(device):
-    """The whole pipeline — split, all_gather, 16 asynchronous all-to-all-v's on RCCL's stream,
-    per-region sorts chained behind them — through the real "nccl" backend with one rank."""
-    import torch
-    import torch.distributed as dist
-    import radx_amd
-    from radx_amd.sharded import HipEngine, ShardedSorter, init_process_group
-    if dist.is_initialized():
-        pytest.skip("a process group already exists in this process")
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    init_process_group(torch.device(device), rank=0, world_size=1)
-    try:
-        n = (1 << 22) + 12345
-        cap = n + 4096
-        eng = HipEngine(cap, 4, 0)
-        sharder = ShardedSorter(eng, exchange_when_alone=True)
-        keys = torch.empty(cap, dtype=torch.int32, device=device)
-        work = torch.empty_like(keys)
-        for step in range(3):  # back-to-back steps reuse work/stage while nothing is synchronised in between
-            radx_amd.generate_u32(keys, seed=77 + step, n=n)
-            before = radx_amd.checksum(keys, n=n)
-            shard, total, send, recv = sharder.sort(keys, work, n)
-            assert total == n
-            assert radx_amd.check_sorted(shard, n=n) == 0
-            assert radx_amd.checksum(shard, n=n) == before
-        small = make_keys("hash", 70001, 4, seed=9)
-        keys[:small.size] = to_dev(small, device)
-        shard, total, _, _ = sharder.sort(keys, work, small.size)
-        assert np.array_equal(to_host(shard), np.sort(small))
-        eng.close()
-    finally:
-        dist.destroy_process_group()
 
 
 @pytest.mark.parametrize("kind,descending", [("signed", False), ("float", True), ("unsigned", True)])
