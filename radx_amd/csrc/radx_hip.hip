@@ -540,19 +540,43 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         for (int j = 0; j < kGroup; ++j) k[j] = skeys[(m0 + j) * kBlock + tid];
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) w[j] = where_s[digit_of<K>(k[j], bit, mask)];
+        uint32_t second_bits = 0;  // bit j: key j of the group lands in its run's second destination tile
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
             const uint32_t s = (m0 + j) * kBlock + tid;
             const uint32_t at = w[j].x + s;
             if (HAS_V) where[m0 + j] = at;
-            if (!guarded || s < valid) {
-                kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];  // last pass restores the key's own bits
-                if (FUSE) {
-                    const uint32_t slot = (digit_of<K>(k[j], bit, mask) << 4) | digit_of<K>(k[j], next_bit, next_mask);
-                    const bool in_first = (at >> LOG_TILE) == w[j].y;
-                    uint32_t* const ctr_at = in_first ? &ctr[(slot >> 2) * 32u + col] : &next_second[slot];
-                    __hip_atomic_fetch_add(ctr_at, in_first ? 1u << ((slot & 3u) << 3) : 1u, __ATOMIC_RELAXED,
+            const bool live = !guarded || s < valid;
+            if (live) kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];  // last pass restores the key's own bits
+            if (FUSE) {
+                const uint32_t slot = (digit_of<K>(k[j], bit, mask) << 4) | digit_of<K>(k[j], next_bit, next_mask);
+                const bool in_first = (at >> LOG_TILE) == w[j].y;
+                if (live && in_first)
+                    __hip_atomic_fetch_add(&ctr[(slot >> 2) * 32u + col], 1u << ((slot & 3u) << 3), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
+                second_bits |= (live && !in_first ? 1u : 0u) << j;
+            }
+        }
+        // Keys for a run's second destination tile share one counter per slot.  A wave's keys are
+        // consecutive in sorted order, so with skewed keys most of its lanes can want the same
+        // counter: the lanes that agree with the first such lane are counted with one add, the
+        // others add for themselves.  Rare for uniform keys (1 run in 16 crosses a tile boundary),
+        // hence the wave-uniform test per group first.
+        if (FUSE && __ballot(second_bits != 0u)) {
+#pragma unroll
+            for (int j = 0; j < kGroup; ++j) {
+                const bool in_second = (second_bits >> j) & 1u;
+                const uint64_t second_lanes = __ballot(in_second);
+                if (second_lanes) {
+                    const uint32_t slot = (digit_of<K>(k[j], bit, mask) << 4) | digit_of<K>(k[j], next_bit, next_mask);
+                    const int leader = __ffsll(static_cast<unsigned long long>(second_lanes)) - 1;
+                    const uint32_t leader_slot = __builtin_amdgcn_readlane(slot, leader);
+                    const uint64_t agree = __ballot(in_second && slot == leader_slot);
+                    if (static_cast<int>(lane) == leader)
+                        __hip_atomic_fetch_add(&next_second[leader_slot], static_cast<uint32_t>(__popcll(agree)),
+                                               __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    else if (in_second && slot != leader_slot)
+                        __hip_atomic_fetch_add(&next_second[slot], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 }
             }
         }
