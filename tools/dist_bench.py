@@ -41,6 +41,9 @@ cases = {
     "99 % one value": lambda: skewed(0.99),
     "99.9 % one value": lambda: skewed(0.999),
     "99.99 % one value": lambda: skewed(0.9999),
+    "2 values, 50/50": lambda: torch.where(torch.rand(n, device=dev, generator=g) < 0.5, 0x12345678, 0x12345668).to(torch.int32),
+    "4 values + 10 % uniform": lambda: torch.where(torch.rand(n, device=dev, generator=g) < 0.1, hashed(),
+                                                   (torch.randint(0, 4, (n,), dtype=torch.int32, device=dev, generator=g) * 0x00110011 + 0x12005600)),
     "small range (0..999)": lambda: torch.randint(0, 1000, (n,), dtype=torch.int32, device=dev, generator=g),
     "only the top digit varies": lambda: torch.randint(0, 16, (n,), dtype=torch.int32, device=dev, generator=g) << 27,
 }
