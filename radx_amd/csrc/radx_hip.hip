@@ -154,6 +154,17 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
     return v;
 }
 
+// Where element `rank` of a rank-ordered LDS array of E-byte elements lives: the index is XORed
+// with its own 128-byte-row number (mod the elements per row).  When every key of a tile has the
+// same digit, thread t's keys have ranks KPT*t .. KPT*t+KPT-1, so a wave's lanes write with a
+// stride of 64 bytes — 2 banks for 64 lanes; the XOR spreads such a stride over all 32 banks,
+// and a wave reading 64 consecutive ranks back still touches every bank twice.
+template <int E>
+__device__ __forceinline__ uint32_t rank_slot(uint32_t rank) {
+    constexpr uint32_t PER_ROW = 128u / E;  // 32 (4-byte) or 16 (8-byte) elements
+    return rank ^ ((rank / PER_ROW) & (PER_ROW - 1u));
+}
+
 // The tile image in LDS used to hand every thread its own 64 consecutive bytes: logical dword
 // (row, c), row = owning thread, c = 0..15, lives at row*16 + ((c/4) ^ ((row >> 2) & 3))*4 + c%4.
 // The XOR on the 16-byte chunk index makes both the coalesced ds_write_b128 (lanes 4r..4r+3 fill
@@ -521,7 +532,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     }
     K* skeys = reinterpret_cast<K*>(stage);
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) skeys[(rank2[i / 2] >> ((i & 1) << 4)) & 0xffffu] = key[i];
+    for (int i = 0; i < KPT; ++i) skeys[rank_slot<sizeof(K)>((rank2[i / 2] >> ((i & 1) << 4)) & 0xffffu)] = key[i];
     __syncthreads();
 
     // Full tiles in the default key order (all but at most one workgroup per launch, and all but
@@ -532,12 +543,17 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     // with 8; uint64 keys alone are fastest one at a time.
     constexpr int kGroup = (sizeof(K) == 8 && !HAS_V) ? 1 : 8;
     const uint32_t col = tid & 31u;
+    // rank_slot(m * 256 + tid) = rank_slot((m & 3) * 256 + tid) + (m >> 2) * 1024: the XOR only
+    // sees index bits 5..9 and only changes bits 0..4, so four bases serve all the reads.
+    uint32_t read_base[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) read_base[q] = rank_slot<sizeof(K)>(q * kBlock + tid);
     uint32_t where[HAS_V ? KPT : 1];
     auto emit = [&](int m0, bool guarded, int restore) {
         K k[kGroup];
         uint2 w[kGroup];
 #pragma unroll
-        for (int j = 0; j < kGroup; ++j) k[j] = skeys[(m0 + j) * kBlock + tid];
+        for (int j = 0; j < kGroup; ++j) k[j] = skeys[read_base[(m0 + j) & 3] + ((m0 + j) >> 2) * (4 * kBlock)];
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) w[j] = where_s[digit_of<K>(k[j], bit, mask)];
         uint32_t second_bits = 0;  // bit j: key j of the group lands in its run's second destination tile
@@ -614,12 +630,12 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     if (HAS_V) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) stage[(rank2[i / 2] >> ((i & 1) << 4)) & 0xffffu] = val[i];
+        for (int i = 0; i < KPT; ++i) stage[rank_slot<4>((rank2[i / 2] >> ((i & 1) << 4)) & 0xffffu)] = val[i];
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < KPT; ++m) {
             const uint32_t s = m * kBlock + tid;
-            if (s < valid) vout[where[m]] = stage[s];
+            if (s < valid) vout[where[m]] = stage[rank_slot<4>((m & 3) * kBlock + tid) + (m >> 2) * (4 * kBlock)];
         }
     }
 }
