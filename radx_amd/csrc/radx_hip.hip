@@ -66,9 +66,15 @@ __device__ __forceinline__ uint32_t tile_of_workgroup(uint32_t bid, uint32_t nwg
     return (x < r ? x * (q + 1u) : r * (q + 1u) + (x - r) * q) + k;
 }
 
+// The digit of (mask + 1) values at `bit`.  For 32-bit keys this is one v_bfe_u32 (the width is
+// the mask's population count, a scalar the compiler hoists); 64-bit keys shift and mask.
 template <typename K>
 __device__ __forceinline__ uint32_t digit_of(K key, int bit, uint32_t mask) {
     return static_cast<uint32_t>(key >> bit) & mask;
+}
+template <>
+__device__ __forceinline__ uint32_t digit_of<uint32_t>(uint32_t key, int bit, uint32_t mask) {
+    return __builtin_amdgcn_ubfe(key, static_cast<uint32_t>(bit), static_cast<uint32_t>(__builtin_popcount(mask)));
 }
 
 // Key orders other than "unsigned ascending" (the reference declares them as
