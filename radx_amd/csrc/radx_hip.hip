@@ -476,7 +476,13 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     // 2. thread-private packed counters.
 #pragma unroll
     for (int r = 0; r < kCtrRows; ++r) ctr[r * kBlock + tid] = 0u;
-    uint32_t rank2[KPT / 2];  // two 16-bit ranks per register (a rank is below the tile size)
+    // Ranks (below the tile size) stay in registers until the keys — and, with a payload, the
+    // values much later — go to LDS.  With a payload they are packed two to a register to ease
+    // the pressure over that long range (uint64 + payload: 83.0 -> 81.1 ms per 2^30 sort);
+    // without one the packing arithmetic costs more than it saves (uint32: 13.34 vs 13.28 ms).
+    constexpr bool PACK = HAS_V;
+    uint32_t rank[PACK ? KPT / 2 : KPT];
+    auto rank_of = [&](int i) { return PACK ? (rank[i / 2] >> ((i & 1) << 4)) & 0xffffu : rank[i]; };
 #pragma unroll
     for (int i = 0; i < KPT; ++i) {
         const uint32_t d = digit_of<K>(key[i], bit, mask);
@@ -484,7 +490,8 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         const uint32_t old = __hip_atomic_fetch_add(&ctr[(d & 7u) * kBlock + tid], 1u << sh,
                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         const uint32_t r = (old >> sh) & 0xffffu;
-        rank2[i / 2] = (i & 1) ? rank2[i / 2] | (r << 16) : r;
+        if (PACK) rank[i / 2] = (i & 1) ? rank[i / 2] | (r << 16) : r;
+        else rank[i] = r;
     }
     __syncthreads();
 
@@ -521,8 +528,9 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     for (int i = 0; i < KPT; ++i) {
         const uint32_t d = digit_of<K>(key[i], bit, mask);
         const uint32_t sh = (d >> 3) << 4;
-        // the sum stays below the tile size, so the add cannot carry into the other half
-        rank2[i / 2] += ((ctr[(d & 7u) * kBlock + tid] >> sh) & 0xffffu) << ((i & 1) << 4);
+        const uint32_t before = (ctr[(d & 7u) * kBlock + tid] >> sh) & 0xffffu;
+        if (PACK) rank[i / 2] += before << ((i & 1) << 4);  // stays below the tile size: no carry into the other half
+        else rank[i] += before;
     }
     if (tid < static_cast<uint32_t>(kRadices)) {
         const uint32_t start = (ctr[(tid & 7u) * kBlock] >> ((tid >> 3) << 4)) & 0xffffu;
@@ -538,7 +546,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     }
     K* skeys = reinterpret_cast<K*>(stage);
 #pragma unroll
-    for (int i = 0; i < KPT; ++i) skeys[rank_slot<sizeof(K)>((rank2[i / 2] >> ((i & 1) << 4)) & 0xffffu)] = key[i];
+    for (int i = 0; i < KPT; ++i) skeys[rank_slot<sizeof(K)>(rank_of(i))] = key[i];
     __syncthreads();
 
     // Full tiles in the default key order (all but at most one workgroup per launch, and all but
@@ -636,7 +644,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     if (HAS_V) {
         __syncthreads();
 #pragma unroll
-        for (int i = 0; i < KPT; ++i) stage[rank_slot<4>((rank2[i / 2] >> ((i & 1) << 4)) & 0xffffu)] = val[i];
+        for (int i = 0; i < KPT; ++i) stage[rank_slot<4>(rank_of(i))] = val[i];
         __syncthreads();
 #pragma unroll
         for (int m = 0; m < KPT; ++m) {
