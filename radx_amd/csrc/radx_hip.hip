@@ -413,7 +413,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     __shared__ __attribute__((aligned(16))) uint32_t stage[kTileDwords];
     __shared__ __attribute__((aligned(16))) uint32_t ctr[kCtrRows * kBlock];  // FUSE: reused as next_first[64][32]
     __shared__ uint32_t next_second[FUSE ? kRadices * kRadices : 1];
-    __shared__ __attribute__((aligned(8))) uint2 where_s[kRadices];  // .x = global base - tile start of the digit, .y = its first destination tile
+    __shared__ __attribute__((aligned(8))) uint2 where_s[kRadices];  // .x = global base - tile start of the digit, .y = last index of its first destination tile
     __shared__ uint32_t wave_tot[kBlock / 64];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -534,7 +534,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     }
     if (tid < static_cast<uint32_t>(kRadices)) {
         const uint32_t start = (ctr[(tid & 7u) * kBlock] >> ((tid >> 3) << 4)) & 0xffffu;
-        where_s[tid] = make_uint2(run_base - start, run_base >> LOG_TILE);
+        where_s[tid] = make_uint2(run_base - start, run_base | (TILE - 1u));
     }
     if (FUSE) {
         // The rank counters are dead once read: every thread clears the column only it read
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
             if (live) kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];  // last pass restores the key's own bits
             if (FUSE) {
                 const uint32_t slot = (digit_of<K>(k[j], bit, mask) << 4) | digit_of<K>(k[j], next_bit, next_mask);
-                const bool in_first = (at >> LOG_TILE) == w[j].y;
+                const bool in_first = at <= w[j].y;
                 if (live && in_first)
                     __hip_atomic_fetch_add(&ctr[(slot >> 2) * 32u + col], 1u << ((slot & 3u) << 3), __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -635,7 +635,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         const uint32_t pick = (tid & 1u) ? odd : even;
         const uint32_t first_sum = (tid & 2u) ? pick >> 16 : pick & 0xffffu;
         const uint32_t second_sum = next_second[tid];
-        const uint32_t dest = where_s[tid >> 4].y;
+        const uint32_t dest = where_s[tid >> 4].y >> LOG_TILE;
         uint32_t* row = next_counts + static_cast<size_t>(dest) * kRadices + (tid & 15u);
         if (first_sum) atomicAdd(row, first_sum);
         if (second_sum) atomicAdd(row + kRadices, second_sum);
