@@ -28,7 +28,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log2n", type=int, default=30, help="log2 of keys per GPU (30 = README headline size)")
-    ap.add_argument("--cpu-log2n", type=int, default=27, help="log2 of the CPU-baseline sample")
+    ap.add_argument("--cpu-log2n", type=int, default=29, help="log2 of the CPU-baseline sample (2^29: about 10 s of host work)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--no-extras", action="store_true", help="skip the other single-GPU configs")
     ap.add_argument("--rehearse-exchange", action="store_true",
