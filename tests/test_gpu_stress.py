@@ -1,0 +1,65 @@
+"""Seeded random stress of the C ABI on the GPU: random sizes, key widths, payloads, bit ranges,
+key orders and distributions (heavy skew included), every result compared bit-for-bit with
+numpy's stable sort of the same field."""
+import os
+
+import numpy as np
+import pytest
+
+from datasets import DISTRIBUTIONS, make_keys
+from test_gpu_sort import ordered_image, to_dev, to_host
+
+pytestmark = pytest.mark.gpu
+
+
+def skewed_keys(rng, n, key_bytes):
+    """A few heavy values (so that digit runs cross tile boundaries with many equal keys) plus noise."""
+    dt = np.uint32 if key_bytes == 4 else np.uint64
+    heavy = rng.integers(0, np.iinfo(dt).max, size=int(rng.integers(1, 5)), dtype=dt)
+    keys = heavy[rng.integers(0, heavy.size, size=n)]
+    noise = rng.random(n) < rng.choice([0.0, 0.001, 0.1, 0.5])
+    keys[noise] = rng.integers(0, np.iinfo(dt).max, size=int(noise.sum()), dtype=dt)
+    return keys
+
+
+@pytest.mark.parametrize("seed", range(int(os.environ.get("RADX_STRESS_SEEDS", "12"))))  # 6 sorts per seed
+def test_random_sorts(device, seed):
+    import torch
+    import radx_amd
+    rng = np.random.default_rng(1000 + seed)
+    for _ in range(6):
+        key_bytes = int(rng.choice([4, 8]))
+        with_vals = bool(rng.integers(0, 2))
+        n = int(rng.choice([rng.integers(1, 5000), rng.integers(5000, 300000), 4096 * int(rng.integers(1, 40))]))
+        if rng.random() < 0.5:
+            keys = skewed_keys(rng, n, key_bytes)
+        else:
+            keys = make_keys(str(rng.choice(DISTRIBUTIONS)), n, key_bytes, seed=int(rng.integers(1, 1 << 30)))
+        bits = key_bytes * 8
+        whole = rng.random() < 0.5
+        begin = 0 if whole else int(rng.integers(0, bits))
+        end = bits if whole else int(rng.integers(begin, bits + 1))
+        kind = str(rng.choice(["unsigned", "signed", "float"])) if whole else "unsigned"
+        descending = bool(rng.integers(0, 2)) if whole else False
+        vals = rng.integers(0, 1 << 32, size=n, dtype=np.uint32)
+
+        s = radx_amd.Sorter(n, key_bytes, 4 if with_vals else 0)
+        s.set_key_order(kind, descending)
+        s.tune(bool(rng.integers(0, 4)))  # mostly fused
+        k = to_dev(keys, device)
+        swap = torch.empty_like(k)
+        v = to_dev(vals, device) if with_vals else None
+        vswap = torch.empty_like(v) if with_vals else None
+        if whole:
+            s.sort(k, swap, v, vswap)
+            field = ordered_image(keys, kind, descending)
+        else:
+            s.sort_bits(k, swap, begin, end, v, vswap)
+            field = (keys >> keys.dtype.type(begin)) & keys.dtype.type((1 << (end - begin)) - 1)
+        torch.cuda.synchronize()
+        order = np.argsort(field, kind="stable")
+        what = "n=%d key_bytes=%d vals=%s bits=[%d,%d) %s desc=%s" % (n, key_bytes, with_vals, begin, end, kind, descending)
+        assert np.array_equal(to_host(k, key_bytes), keys[order]), what
+        if with_vals:
+            assert np.array_equal(to_host(v), vals[order]), what
+        s.close()
