@@ -119,6 +119,11 @@ def pmc_traffic():
 
 def main():
     args = parse()
+    # stdout carries exactly one line, the JSON: anything libraries print while the benchmark runs
+    # (RCCL prints a version banner to stdout when its first communicator is created) goes to stderr
+    sys.stdout.flush()
+    json_out = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import radx_amd
@@ -304,7 +309,10 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.cpu_log2n)
         elif world == 1:
             out["cpu_baseline"] = None
+        sys.stdout.flush()
+        os.dup2(json_out, 1)
         print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
 
     engine.close()
     if multi:
