@@ -4,15 +4,25 @@
   python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n L]
 
 One step = one complete sort (all 8 four-bit passes) of one batch of 2^L uniform uint32 keys
-per GPU that is already resident in HBM.  N > 1 is launched by torch.distributed.run, one rank
-per GPU; a step is then the split pass on the top digit + the all-to-all-v exchange over RCCL +
-the 7 local passes, pipelined per sub-bucket, and the per-GPU batch stays 2^L (weak scaling).  Every step sorts a DIFFERENT pre-generated batch, so
-no step ever sees already-sorted input.  Rank 0 prints one JSON line.
+per GPU that is already resident in HBM.  N > 1 runs one rank per GPU: either this script is
+started once per rank by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the
+environment), or — started plainly as `python bench.py --gpus N` — it starts the N ranks itself as
+child processes before anything touches a GPU, relays rank 0's JSON line and exits with the worst
+child status.  A step is then the split pass on the top digit + the all-to-all-v exchange over
+RCCL + the 7 local passes, pipelined per sub-bucket, and the per-GPU batch stays 2^L (weak
+scaling).  Every step sorts a DIFFERENT pre-generated batch, so no step ever sees already-sorted
+input.  Rank 0 prints one JSON line.
+
+The timed region runs with per-kernel event profiling OFF; a second, untimed loop over freshly
+generated batches collects the per-launch kernel times behind `roofline`.
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -34,7 +44,64 @@ def parse():
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="on one GPU, run the N > 1 code path (RCCL process group of one rank, split + "
                          "16 all-to-all-v's + per-region local passes) instead of the plain sort")
+    ap.add_argument("--print-launch", action="store_true",
+                    help="with --gpus N > 1 and no WORLD_SIZE in the environment: print the child "
+                         "commands and rank environments as JSON instead of starting them")
     return ap.parse_args()
+
+
+RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+
+
+def launch_plan(n_ranks, argv, port=None):
+    """Command and per-rank environment overrides for n_ranks children of this script."""
+    if port is None:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+    cmd = [sys.executable, "-u", os.path.abspath(__file__)] + [a for a in argv if a != "--print-launch"]
+    envs = [{"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n_ranks), "LOCAL_WORLD_SIZE": str(n_ranks),
+             "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)} for r in range(n_ranks)]
+    return cmd, envs
+
+
+def launch_ranks(n_ranks, argv):
+    """Start one child per rank (this process never initialises a GPU and never execs), relay rank
+    0's stdout, wait for all, and return the worst exit status.  When a rank fails the others get
+    a grace period to notice (their collectives error out) and are then terminated by PID."""
+    cmd, envs = launch_plan(n_ranks, argv)
+    procs = []
+    for r, over in enumerate(envs):
+        env = dict(os.environ)
+        env.update(over)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # rank 0 owns stdout (the JSON line); the other ranks' stdout joins stderr
+        procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
+    worst, failed_at = 0, None
+    live = set(range(n_ranks))
+    while live:
+        for r in sorted(live):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            live.discard(r)
+            if rc != 0:
+                print("bench.py: rank %d exited with status %d" % (r, rc), file=sys.stderr)
+                worst = worst or (rc if rc > 0 else 128 - rc)
+                failed_at = failed_at or time.monotonic()
+        if failed_at and live and time.monotonic() - failed_at > 30.0:
+            for r in sorted(live):
+                procs[r].terminate()
+            deadline = time.monotonic() + 10.0
+            for r in sorted(live):
+                try:
+                    procs[r].wait(max(0.1, deadline - time.monotonic()))
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+                    procs[r].wait()
+            live.clear()
+        time.sleep(0.05)
+    return worst
 
 
 def cpu_baseline(log2n):
@@ -89,6 +156,7 @@ def other_configs(dev):
             else:
                 radx_amd.generate_u64(k, vals[i], seed=1000 + i)
         s = radx_amd.Sorter(n, kb, vb)
+        before = radx_amd.checksum(keys[steps])  # multiset of the last timed batch, before its sort
         s.sort(keys[0], swap, vals[0] if vb else None, vswap)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -96,7 +164,14 @@ def other_configs(dev):
             s.sort(keys[i], swap, vals[i] if vb else None, vswap)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / steps
+        # sorted (with a payload: and stable, the payload being the original index), same multiset
         ok = radx_amd.check_sorted(keys[steps], vals[steps] if vb else None) == 0
+        ok = ok and radx_amd.checksum(keys[steps]) == before
+        if vb:
+            # every payload still names the input slot its key came from: regenerate the batch
+            # into the first slot and compare regenerated[payload[i]] with the sorted key i
+            radx_amd.generate_u64(keys[0], vals[0], seed=1000 + steps)
+            ok = ok and bool(torch.equal(keys[0][vals[steps].long()], keys[steps]))
         bytes_per_elem = (kb * 2) * 2 * (kb + vb)  # passes x (read + write) x element bytes
         res[name] = {"ms_per_sort": round(dt * 1e3, 4), "G_elements_per_s": round(n / dt / 1e9, 3),
                      "algorithmic_bytes_per_element": bytes_per_elem,
@@ -107,18 +182,36 @@ def other_configs(dev):
     return res
 
 
+def kernel_source_sha():
+    with open(os.path.join(ROOT, "radx_amd", "csrc", "radx_hip.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
 def pmc_traffic():
-    """HBM bytes per scatter launch from the committed rocprofv3 PMC passes, if present."""
+    """HBM bytes per scatter launch from the committed rocprofv3 PMC passes (counters cannot be
+    read from inside the run).  The record carries the hash of the kernel source it was taken
+    with; a record taken with other kernels than the ones being timed is not reported."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
         with open(path) as f:
-            return json.load(f)
+            rec = json.load(f)
     except (OSError, ValueError):
-        return None
+        return None, "no PMC record"
+    if rec.get("kernel_source_sha") != kernel_source_sha():
+        return None, "PMC record is stale: taken with kernel source %s, timing %s" % (
+            rec.get("kernel_source_sha"), kernel_source_sha())
+    return rec.get("scatter_bytes_per_launch"), "profiles/pmc_traffic.json (%s)" % rec.get("tag")
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # Started plainly: this process becomes the launcher.  Nothing here touches a GPU.
+        if args.print_launch:
+            cmd, envs = launch_plan(args.gpus, sys.argv[1:])
+            print(json.dumps({"cmd": cmd, "env": envs}))
+            return 0
+        return launch_ranks(args.gpus, sys.argv[1:])
     # stdout carries exactly one line, the JSON: anything libraries print while the benchmark runs
     # (RCCL prints a version banner to stdout when its first communicator is created) goes to stderr
     sys.stdout.flush()
@@ -132,11 +225,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with `python -m torch.distributed.run "
-                     "--nproc-per-node %d ...`" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world  # the launcher (ours or torch.distributed.run) decides the number of ranks
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.rehearse_exchange  # the split / exchange / per-region path
@@ -164,7 +253,7 @@ def main():
     for i in range(pool_n):
         fill(i, i)
     engine = HipEngine(cap, 4, local_rank)
-    sharder = ShardedSorter(engine, exchange_when_alone=True, profile=True) if multi else None
+    sharder = ShardedSorter(engine, exchange_when_alone=True) if multi else None
     checks = radx_amd.checksum(pool[(K + W - 1) % pool_n], n=n)  # of the last timed step's input
 
     def step(i):
@@ -182,7 +271,6 @@ def main():
     for w in range(W):
         step(w % pool_n)
     fence()
-    engine.sorter.profile(True)
     last_len = n
     if wall_mode:
         t0 = time.perf_counter()
@@ -207,10 +295,6 @@ def main():
             fence()
             elapsed += e0.elapsed_time(e1) / 1e3
         timing = "per-step HIP events (batch pool of %d regenerated between steps)" % pool_n
-    kt = engine.sorter.kernel_times()
-    engine.sorter.profile(False)
-    timeline = sharder.timeline() if multi else None
-
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -244,6 +328,21 @@ def main():
         dist.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(v.item())
 
+    # Per-launch kernel times, outside the timed region: the same steps again on freshly generated
+    # batches with every launch bracketed by HIP events on its own stream.
+    P = min(K, 5)
+    engine.sorter.profile(True)
+    if multi:
+        sharder.profile = True
+    for s in range(P):
+        i = s % pool_n
+        fill(i, W + K + s)
+        step(i)
+        fence()
+    kt = engine.sorter.kernel_times()
+    engine.sorter.profile(False)
+    timeline = sharder.timeline() if multi else None
+
     # device-to-device copy ceiling of this GPU, same run
     src, dst = pool[0], work
     torch.cuda.synchronize()
@@ -269,9 +368,9 @@ def main():
         # algorithmic bytes of the scatter launches: every pass reads and writes every key once.
         # One launch covers n keys on one GPU and one region (n * N / 16 keys on average) on N > 1.
         avg_ms = scatter_ms / max(1, scatter_launches)
-        alg_bytes = 8 * 2.0 * 4 * n * K / max(1, scatter_launches)
+        alg_bytes = 8 * 2.0 * 4 * n * P / max(1, scatter_launches)
         achieved = alg_bytes / (avg_ms / 1e3) / 1e9 if avg_ms > 0 else 0.0
-        traffic = pmc_traffic()
+        traffic, traffic_source = pmc_traffic()
         out = {
             "metric": "Gkeys/s (uint32) at 1/2/4/8 MI355X; achieved HBM GB/s vs peak",
             "value": round(value, 3), "unit": "Gkeys/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -293,9 +392,11 @@ def main():
             "roofline": {
                 "kernel": "scatter_kernel<uint32>", "bound": "hbm", "achieved": round(achieved, 1),
                 "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": round(achieved / PEAK_HBM_GBPS, 4),
-                "traffic": traffic.get("scatter_bytes_per_launch") if traffic else None,
+                "traffic": traffic if args.log2n == 30 and not multi else None,
+                "traffic_source": traffic_source,
                 "launches": scatter_launches, "avg_launch_ms": round(avg_ms, 4),
-                "algorithmic_bytes_per_launch": alg_bytes},
+                "algorithmic_bytes_per_launch": alg_bytes,
+                "timed_by": "HIP events around every launch, %d profiled steps after the timed region" % P},
         }
         if multi:
             # xGMI traffic of one step, reported beside the HBM figures (never part of them)
@@ -321,4 +422,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

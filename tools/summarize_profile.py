@@ -9,6 +9,7 @@ with the scatter's store width, and on hist_kernel / checksum_kernel, which read
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import shutil
@@ -55,7 +56,10 @@ def corrected(*needles):
     return rd, wr
 
 
-out = {"tag": tag, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+with open(os.path.join(root, "radx_amd", "csrc", "radx_hip.hip"), "rb") as f:
+    kernel_sha = hashlib.sha256(f.read()).hexdigest()[:16]
+# bench.py reports this record's traffic only while the kernel source still has this hash
+out = {"tag": tag, "kernel_source_sha": kernel_sha, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
        "`python3 bench.py --steps 1 --warmup 0 --no-cpu`, 2^30 uint32 keys",
        "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); WRITE_SIZE exact"}
 # scatter_kernel<K, HAS_V, FUSE>: the fused variant (7 of 8 passes) also counts the next pass's digits
