@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -29,20 +30,29 @@
 
 namespace {
 
-// a reusable barrier for the host threads
+// a reusable barrier for the host threads; abort() releases every waiter, now and later
 class Barrier {
 public:
     explicit Barrier(int n) : n_(n) {}
-    void wait() {
+    // false when the barrier was aborted: the caller's peers will not all arrive
+    bool wait() {
         std::unique_lock<std::mutex> lock(m_);
+        if (aborted_) return false;
         const int gen = gen_;
         if (++count_ == n_) { count_ = 0; ++gen_; cv_.notify_all(); }
-        else cv_.wait(lock, [&] { return gen != gen_; });
+        else cv_.wait(lock, [&] { return gen != gen_ || aborted_; });
+        return !aborted_;
+    }
+    void abort() {
+        std::lock_guard<std::mutex> lock(m_);
+        aborted_ = true;
+        cv_.notify_all();
     }
 private:
     std::mutex m_;
     std::condition_variable cv_;
     int n_, count_ = 0, gen_ = 0;
+    bool aborted_ = false;
 };
 
 struct Shared {
@@ -53,6 +63,12 @@ struct Shared {
     std::vector<uint64_t> sumBefore, mixBefore, sumAfter, mixAfter, shardLen, violations, strangers;
     std::vector<double> ms;
     std::vector<std::string> errors;
+    std::vector<ncclComm_t>* comms = nullptr;
+    std::atomic<bool> aborted{false};
+};
+
+struct PeerFailed : std::runtime_error {
+    PeerFailed() : std::runtime_error("stopped: another rank failed") {}
 };
 
 void hipOk(hipError_t e, const char* what) { radx::check_hip(e, what); }
@@ -104,11 +120,11 @@ void worker(int rank, ncclComm_t comm, Shared* sh, Barrier* barrier) {
                     }
                 }
                 hipOk(hipStreamSynchronize(stream), "sync");
-                barrier->wait();
+                if (!barrier->wait()) throw PeerFailed();
                 const auto t0 = std::chrono::steady_clock::now();
                 shard = sorter.sort(keys, work, stage, n, stream);
                 hipOk(hipStreamSynchronize(stream), "sync");
-                barrier->wait();
+                if (!barrier->wait()) throw PeerFailed();
                 if (it) sh->ms[rank] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             }
             sh->shardLen[rank] = shard;
@@ -130,8 +146,17 @@ void worker(int rank, ncclComm_t comm, Shared* sh, Barrier* barrier) {
         }
         hipOk(hipFree(keys), "hipFree"); hipOk(hipFree(work), "hipFree"); hipOk(hipFree(stage), "hipFree");
         hipOk(hipStreamDestroy(stream), "hipStreamDestroy");
+    } catch (const PeerFailed&) {
+        // unwound by the first failing rank; its message is the one worth printing
     } catch (const std::exception& e) {
         sh->errors[rank] = e.what();
+        // The other ranks are, or soon will be, blocked in the barrier or inside an RCCL call
+        // waiting for this one: release the barrier and abort every communicator so that all
+        // threads unwind and main() can report the error instead of hanging.
+        if (!sh->aborted.exchange(true)) {
+            barrier->abort();
+            for (ncclComm_t c : *sh->comms) (void)ncclCommAbort(c);
+        }
     }
 }
 
@@ -168,11 +193,12 @@ int main(int argc, char** argv) {
     for (int r = 0; r < G; ++r) devs[r] = r;
     if (ncclCommInitAll(comms.data(), G, devs.data()) != ncclSuccess) { fprintf(stderr, "ncclCommInitAll failed\n"); return 1; }
 
+    sh.comms = &comms;
     Barrier barrier(G);
     std::vector<std::thread> threads;
     for (int r = 0; r < G; ++r) threads.emplace_back(worker, r, comms[r], &sh, &barrier);
     for (auto& t : threads) t.join();
-    for (int r = 0; r < G; ++r) ncclCommDestroy(comms[r]);
+    if (!sh.aborted) for (int r = 0; r < G; ++r) ncclCommDestroy(comms[r]);  // aborted communicators are already gone
 
     bool pass = true;
     for (int r = 0; r < G; ++r)

@@ -157,6 +157,10 @@ namespace radx {
             const std::size_t need = n * static_cast<std::size_t>(keyBytes);
             if (n && (inputInterface->keysBufferInfo.range < need || inputInterface->swapBufferInfo.range < need))
                 throw Error(static_cast<int>(hipErrorInvalidValue), "Radix::command: keys/swap range smaller than elementCount");
+            const std::size_t needValues = n * static_cast<std::size_t>(valueBytes);
+            if (n && valueBytes && (inputInterface->valuesBufferInfo.range < needValues ||
+                                    inputInterface->valuesSwapBufferInfo.range < needValues))
+                throw Error(static_cast<int>(hipErrorInvalidValue), "Radix::command: values/valuesSwap range smaller than elementCount");
             res = radx_hip_sort(internalInterface->handle(), inputInterface->keysBufferInfo.address(),
                                 inputInterface->swapBufferInfo.address(), inputInterface->valuesBufferInfo.address(),
                                 inputInterface->valuesSwapBufferInfo.address(), n, cmdBuf.stream);

@@ -786,23 +786,23 @@ struct Geometry {
     uint32_t num_tiles;   // grid
     uint32_t num_groups;  // scan workgroups: ceil(num_tiles / 256)
 };
-Geometry geometry_for(uint64_t n, int key_bytes) {
-    Geometry g;
+constexpr Geometry geometry_for(uint64_t n, int key_bytes) {
+    Geometry g{};
     g.tile = static_cast<uint32_t>(kTileDwords * 4 / key_bytes);
     const uint64_t nn = n ? n : 1;
     g.num_tiles = static_cast<uint32_t>((nn + g.tile - 1) / g.tile);
     g.num_groups = (g.num_tiles + kScanBlocks - 1) / kScanBlocks;
     return g;
 }
-size_t align256(size_t b) { return (b + 255u) & ~static_cast<size_t>(255u); }
+constexpr size_t align256(size_t b) { return (b + 255u) & ~static_cast<size_t>(255u); }
 
 struct ScratchLayout {
     size_t counts[2], offsets, group_sums, digit_starts, total;
 };
-ScratchLayout layout_for(uint64_t max_n, int key_bytes) {
+constexpr ScratchLayout layout_for(uint64_t max_n, int key_bytes) {
     const Geometry g = geometry_for(max_n, key_bytes);
     const size_t table = align256(static_cast<size_t>(g.num_tiles) * kRadices * 4);
-    ScratchLayout l;
+    ScratchLayout l{};
     l.counts[0] = 0;
     l.counts[1] = table;
     l.offsets = 2 * table;
@@ -847,6 +847,7 @@ struct radx_hip_sorter {
     uint32_t* group_sums = nullptr;
     uint32_t* digit_starts = nullptr;
     int cur = 0;            // counts[cur] holds the histogram of the last pass run
+    uint64_t tables_n = 0;  // element count of the pass whose tables the scratch holds (0: none yet)
     bool chained = false;   // counts[cur ^ 1] holds a fused histogram for the next pass
     uint64_t chained_n = 0;
     int chained_bit = 0, chained_bits = 0;
@@ -858,6 +859,35 @@ struct radx_hip_sorter {
 };
 
 namespace {
+
+// Points the sorter's table pointers into `base`, laid out by layout_for.
+void bind_scratch(radx_hip_sorter* s, char* base) {
+    s->scratch = base;
+    s->counts[0] = reinterpret_cast<uint32_t*>(base + s->layout.counts[0]);
+    s->counts[1] = reinterpret_cast<uint32_t*>(base + s->layout.counts[1]);
+    s->offsets = reinterpret_cast<uint32_t*>(base + s->layout.offsets);
+    s->group_sums = reinterpret_cast<uint32_t*>(base + s->layout.group_sums);
+    s->digit_starts = reinterpret_cast<uint32_t*>(base + s->layout.digit_starts);
+}
+
+// Folds finished launch timings into the per-kind sums and recycles their events.  wait: block
+// on launches still running; otherwise only launches whose stop event has fired are taken.
+hipError_t harvest_timings(radx_hip_sorter* s, bool wait) {
+    size_t kept = 0;
+    hipError_t first_error = hipSuccess;
+    for (auto& t : s->pending) {
+        hipError_t e = wait ? hipEventSynchronize(t.stop) : hipEventQuery(t.stop);
+        if (e == hipErrorNotReady) { s->pending[kept++] = t; continue; }
+        float f = 0.f;
+        if (e == hipSuccess) e = hipEventElapsedTime(&f, t.start, t.stop);
+        if (e == hipSuccess) { s->ms[t.kind] += f; s->launches[t.kind] += 1; }
+        else if (first_error == hipSuccess) first_error = e;
+        s->pool.push_back(t);
+    }
+    s->pending.resize(kept);
+    return first_error;
+}
+constexpr size_t kMaxPendingTimings = 1024;  // ~40 sorts' worth; beyond it finished ones are folded in
 
 // Brackets one launch with events when profiling is on.
 class LaunchTimer {
@@ -873,6 +903,8 @@ public:
         if (!active_) return;
         (void)hipEventRecord(t_.stop, stream_);
         s_->pending.push_back(t_);
+        // a caller that profiles for a long time without reading the times must not grow the list forever
+        if (s_->pending.size() >= kMaxPendingTimings) (void)harvest_timings(s_, s_->pending.size() >= 4 * kMaxPendingTimings);
     }
 private:
     radx_hip_sorter* s_;
@@ -931,6 +963,7 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
                                0, 0u, static_cast<uint32_t*>(nullptr), a.order_in, a.order_out);
     }
     RADX_TRY(hipGetLastError());
+    s->tables_n = a.n;
     s->chained = a.fuse_next;
     s->chained_n = a.n;
     s->chained_bit = a.next_bit;
@@ -971,6 +1004,15 @@ int check_digit(const radx_hip_sorter* s, int bit, int num_bits) {
     return 0;
 }
 
+// A pass over no elements launches nothing, but it is still "the last pass": every digit's run is
+// empty, so the 17 run starts become zeros (in stream order) and no tables are left to read.
+int empty_pass(radx_hip_sorter* s, hipStream_t stream) {
+    RADX_TRY(hipMemsetAsync(s->digit_starts, 0, (kRadices + 1) * sizeof(uint32_t), stream));
+    s->tables_n = 0;
+    s->chained = false;
+    return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1005,11 +1047,10 @@ int radx_hip_create(int device, uint64_t max_n, int key_bytes, int value_bytes, 
     s->layout = layout_for(max_n, key_bytes);
     const hipError_t e = hipMalloc(reinterpret_cast<void**>(&s->scratch), s->layout.total);
     if (e != hipSuccess) { delete s; return fail(e, "hipMalloc(scratch)"); }
-    s->counts[0] = reinterpret_cast<uint32_t*>(s->scratch + s->layout.counts[0]);
-    s->counts[1] = reinterpret_cast<uint32_t*>(s->scratch + s->layout.counts[1]);
-    s->offsets = reinterpret_cast<uint32_t*>(s->scratch + s->layout.offsets);
-    s->group_sums = reinterpret_cast<uint32_t*>(s->scratch + s->layout.group_sums);
-    s->digit_starts = reinterpret_cast<uint32_t*>(s->scratch + s->layout.digit_starts);
+    bind_scratch(s, s->scratch);
+    // tables read back before any pass has run are zeros, never uninitialised memory
+    const hipError_t z = hipMemset(s->scratch, 0, s->layout.total);
+    if (z != hipSuccess) { (void)hipFree(s->scratch); delete s; return fail(z, "hipMemset(scratch)"); }
     *out = s;
     return 0;
 }
@@ -1017,7 +1058,7 @@ int radx_hip_create(int device, uint64_t max_n, int key_bytes, int value_bytes, 
 int radx_hip_destroy(radx_hip_sorter* s) {
     if (!s) return 0;
     DeviceGuard guard(s->device);
-    for (auto& t : s->pending) { (void)hipEventSynchronize(t.stop); s->pool.push_back(t); }
+    (void)harvest_timings(s, true);
     for (auto& t : s->pool) { (void)hipEventDestroy(t.start); (void)hipEventDestroy(t.stop); }
     const hipError_t e = s->scratch ? hipFree(s->scratch) : hipSuccess;
     delete s;
@@ -1053,9 +1094,9 @@ int radx_hip_pass_fused(radx_hip_sorter* s, const void* keys_in, void* keys_out,
     if (fuse_next) if (const int rc = check_digit(s, next_bit, next_num_bits)) return rc;
     if (use_fused_counts && !(s->chained && s->chained_n == n && s->chained_bit == bit && s->chained_bits == num_bits))
         return bad_arg("no fused histogram for this digit and n: the previous pass did not produce one");
-    if (n == 0) return 0;
     DeviceGuard guard(s->device);
     RADX_TRY(guard.status());
+    if (n == 0) return empty_pass(s, static_cast<hipStream_t>(stream));
     PassArgs a{keys_in, keys_out, vals_in, vals_out, static_cast<uint32_t>(n), bit, num_bits,
                use_fused_counts != 0, fuse_next, fuse_next ? next_bit : 0, fuse_next ? next_num_bits : 0, 0, 0};
     return run_pass(s, a, static_cast<hipStream_t>(stream));
@@ -1148,9 +1189,9 @@ int radx_hip_msd_split(radx_hip_sorter* s, const void* keys_in, void* keys_out, 
                        void* vals_out, uint64_t n, int log2_ranks, void* stream) {
     if (const int rc = check_buffers(s, keys_in, keys_out, vals_in, vals_out, n)) return rc;
     if (log2_ranks < 0 || log2_ranks > kDigitBits) return bad_arg("log2_ranks must be 0..4");
-    if (n == 0) return 0;
     DeviceGuard guard(s->device);
     RADX_TRY(guard.status());
+    if (n == 0) return empty_pass(s, static_cast<hipStream_t>(stream));
     const int order = s->key_order | ((log2_ranks & 3) << kOrderRotShift);  // rotating by 0 or 4 is the identity
     PassArgs a{keys_in, keys_out, vals_in, vals_out, static_cast<uint32_t>(n), s->key_bytes * 8 - kDigitBits,
                kDigitBits, false, false, 0, 0, order, order};
@@ -1175,6 +1216,7 @@ int radx_hip_geometry(const radx_hip_sorter* s, uint64_t n, uint32_t* tile_keys,
 int radx_hip_copy_tables(radx_hip_sorter* s, uint64_t n, uint32_t* counts, uint32_t* offsets, void* stream) {
     if (!s) return bad_arg("sorter is NULL");
     if (n == 0 || n > s->max_n) return bad_arg("n out of range");
+    if (s->tables_n != n) return bad_arg("the scratch holds no tables for this n: the last pass ran on a different element count (or none ran)");
     DeviceGuard guard(s->device);
     RADX_TRY(guard.status());
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1211,15 +1253,7 @@ int radx_hip_kernel_times(radx_hip_sorter* s, double ms[3], uint64_t launches[3]
     if (!s) return bad_arg("sorter is NULL");
     DeviceGuard guard(s->device);
     RADX_TRY(guard.status());
-    for (auto& t : s->pending) {
-        RADX_TRY(hipEventSynchronize(t.stop));
-        float f = 0.f;
-        RADX_TRY(hipEventElapsedTime(&f, t.start, t.stop));
-        s->ms[t.kind] += f;
-        s->launches[t.kind] += 1;
-        s->pool.push_back(t);
-    }
-    s->pending.clear();
+    RADX_TRY(harvest_timings(s, true));
     for (int i = 0; i < 3; ++i) {
         if (ms) ms[i] = s->ms[i];
         if (launches) launches[i] = s->launches[i];
@@ -1230,6 +1264,23 @@ int radx_hip_kernel_times(radx_hip_sorter* s, double ms[3], uint64_t launches[3]
 }
 
 namespace {
+// The free functions below take raw device pointers and no sorter handle: each launches on the
+// device that owns its buffer, whatever device is current on the calling thread.
+int device_of(const void* p, int* device) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, p) != hipSuccess) {
+        (void)hipGetLastError();
+        return bad_arg("buffer is not memory HIP knows (hipMalloc / hipHostMalloc)");
+    }
+    *device = attr.device;
+    return 0;
+}
+#define RADX_ON_DEVICE_OF(ptr)                                     \
+    int dev_ = 0;                                                  \
+    if (const int rc_ = device_of((ptr), &dev_)) return rc_;       \
+    DeviceGuard guard_(dev_);                                      \
+    RADX_TRY(guard_.status())
+
 int log2_or_minus1(uint32_t v) {
     if (v == 0 || (v & (v - 1))) return -1;
     int l = 0;
@@ -1244,6 +1295,7 @@ int radx_hip_indiction(uint32_t* ptrs, void* cache, const void* in, uint64_t n, 
     if (n > kMaxElements) return bad_arg("n must be < 2^32");
     if ((cache == nullptr) != (in == nullptr)) return bad_arg("cache and in go together");
     if (cache && (elem_bytes == 0 || elem_bytes % 4)) return bad_arg("elem_bytes must be a positive multiple of 4");
+    RADX_ON_DEVICE_OF(ptrs);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool wide = cache && elem_bytes % 16 == 0 && aligned16(cache) && aligned16(in);
     if (wide)
@@ -1264,6 +1316,7 @@ int radx_hip_permutation(void* in, const void* cache, const uint32_t* ptrs, uint
     if (in == cache) return bad_arg("in and cache are the same buffer");
     if (n > kMaxElements) return bad_arg("n must be < 2^32");
     if (elem_bytes == 0 || elem_bytes % 4) return bad_arg("elem_bytes must be a positive multiple of 4");
+    RADX_ON_DEVICE_OF(in);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (elem_bytes % 16 == 0 && aligned16(in) && aligned16(cache)) {
         const uint32_t words = static_cast<uint32_t>(elem_bytes / 16);
@@ -1281,6 +1334,7 @@ int radx_hip_permutation(void* in, const void* cache, const uint32_t* ptrs, uint
 int radx_hip_generate_u32(void* keys, uint64_t n, uint32_t seed, void* stream) {
     if (n == 0) return 0;
     if (!keys) return bad_arg("keys is NULL");
+    RADX_ON_DEVICE_OF(keys);
     hipLaunchKernelGGL(generate_u32_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<uint32_t*>(keys), n, seed);
     RADX_TRY(hipGetLastError());
@@ -1290,6 +1344,7 @@ int radx_hip_generate_u32(void* keys, uint64_t n, uint32_t seed, void* stream) {
 int radx_hip_generate_u64(void* keys, void* vals, uint64_t n, uint32_t seed, void* stream) {
     if (n == 0) return 0;
     if (!keys) return bad_arg("keys is NULL");
+    RADX_ON_DEVICE_OF(keys);
     hipLaunchKernelGGL(generate_u64_kernel, dim3(4096), dim3(256), 0, static_cast<hipStream_t>(stream),
                        static_cast<uint64_t*>(keys), static_cast<uint32_t*>(vals), n, seed);
     RADX_TRY(hipGetLastError());
@@ -1303,6 +1358,7 @@ int radx_hip_check_sorted(const void* keys, const void* vals, uint64_t n, int ke
     *violations = 0;
     if (n < 2) return 0;
     if (!keys) return bad_arg("keys is NULL");
+    RADX_ON_DEVICE_OF(keys);
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned long long* d = nullptr;
     RADX_TRY(hipMalloc(reinterpret_cast<void**>(&d), sizeof(unsigned long long)));
@@ -1331,6 +1387,7 @@ int radx_hip_checksum(const void* keys, uint64_t n, int key_bytes, uint64_t out[
     out[0] = out[1] = out[2] = 0;
     if (n == 0) return 0;
     if (!keys) return bad_arg("keys is NULL");
+    RADX_ON_DEVICE_OF(keys);
     hipStream_t st = static_cast<hipStream_t>(stream);
     unsigned long long* d = nullptr;
     RADX_TRY(hipMalloc(reinterpret_cast<void**>(&d), 3 * sizeof(unsigned long long)));

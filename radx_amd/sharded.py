@@ -55,6 +55,8 @@ class HipEngine:
     def msd_split(self, src, dst, n, log2_ranks):
         """Stable partition of src[:n] into dst[:n] on the top digit, runs in (sub-bucket, rank)
         order; returns the 16 run starts followed by n."""
+        if n == 0:  # a rank with nothing to contribute: 16 empty runs (the C ABI reports the same)
+            return np.zeros(17, dtype=np.uint32)
         self.sorter.msd_split(src, dst, log2_ranks, n=n)
         return self.sorter.digit_starts()
 

@@ -199,6 +199,65 @@ def test_sharded_sorter_every_rank_replayed(device, world, key_bytes, dist_name)
     assert np.array_equal(np.concatenate(whole), np.sort(np.concatenate(inputs)))
 
 
+def test_empty_split_reports_empty_runs(device):
+    """A split (or pass) over zero elements leaves 17 zero run starts, not the previous pass's."""
+    import torch
+    import radx_amd
+    n = 5000
+    s = radx_amd.Sorter(n, 4, 0)
+    src = to_dev(make_keys("uniform", n, 4, seed=1), device)
+    dst = torch.empty_like(src)
+    assert not s.digit_starts().any()          # fresh sorter: zeros, not uninitialised memory
+    s.msd_split(src, dst, 2)
+    assert s.digit_starts()[16] == n
+    s.msd_split(src, dst, 2, n=0)
+    assert not s.digit_starts().any()
+    with pytest.raises(radx_amd.RadxError):    # and no tables are left to read for the old n
+        s.tables(n)
+    s.run_pass(src, dst, bit=0)
+    assert s.digit_starts()[16] == n
+    s.run_pass(src, dst, bit=0, n=0)
+    assert not s.digit_starts().any()
+    s.close()
+
+
+@pytest.mark.parametrize("empty_rank", [0, 2])
+def test_sharded_sorter_with_an_empty_rank(device, empty_rank):
+    """One rank contributes no keys: its 16 run lengths are zeros for every rank's plan, it still
+    takes part in every exchange and receives its shard of the others' keys."""
+    import torch
+    from radx_amd.sharded import HipEngine, ShardedSorter
+    world, b = 4, 2
+    sizes = [30000 + 7 * r for r in range(world)]
+    sizes[empty_rank] = 0
+    cap = sum(sizes) + 64
+    eng = HipEngine(cap, 4, 0)
+    inputs = [make_keys("hash", sizes[r], 4, seed=500 + r) for r in range(world)]
+    split_bufs, starts = [], []
+    for r in range(world):
+        src = to_dev(inputs[r], device) if sizes[r] else torch.empty(4, dtype=torch.int32, device=device)
+        dst = torch.empty_like(src)
+        starts.append(eng.msd_split(src, dst, sizes[r], b).astype(np.int64))
+        split_bufs.append(dst)
+    assert not starts[empty_rank].any()
+    whole = []
+    for r in range(world):
+        keys = torch.zeros(cap, dtype=torch.int32, device=device)
+        if sizes[r]:
+            keys[:sizes[r]] = to_dev(inputs[r], device)
+        work = torch.zeros(cap, dtype=torch.int32, device=device)
+        split_bufs[r] = work
+        sharder = ShardedSorter(eng, exchange_when_alone=True, dist=ReplayDist(r, world, split_bufs, starts))
+        shard, total, send, recv = sharder.sort(keys, work, sizes[r])
+        torch.cuda.synchronize()
+        assert int(send.sum()) == sizes[r] and recv[empty_rank] == 0
+        got = to_host(shard).copy()
+        assert got.size == total and np.all((got >> np.uint32(30)) == r)
+        whole.append(got)
+    eng.close()
+    assert np.array_equal(np.concatenate(whole), np.sort(np.concatenate(inputs)))
+
+
 @pytest.mark.parametrize("kind,descending", [("signed", False), ("float", True), ("unsigned", True)])
 def test_sharded_sorter_follows_key_order(device, kind, descending):
     """With a key order set on the engine's sorter the split digit, the shard boundaries and the

@@ -75,10 +75,14 @@ def check_geometry(s, n, cfg):
 
 
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("n", [1000, 4096, 3 * 4096 + 17, 70000, 16 * 4096 + 1])
+@pytest.mark.parametrize("n", [1000, 4096, 3 * 4096 + 17, 70000, 16 * 4096 + 1, 300 * 4096 + 5, 1027 * 4096 + 99])
 def test_u32_every_pass_matches_oracle(device, n, fused):
     """Histogram table, scanned offsets table and scattered output after EACH pass — with the
-    histogram kernel every pass, and with the histogram accumulated by the previous scatter."""
+    histogram kernel every pass, and with the histogram accumulated by the previous scatter.
+    The two largest sizes have more than 256 tiles, i.e. more than one scan workgroup: the
+    second-level scan kernel and the two-part offsets (within-group scan + group base) are
+    compared table for table with the reference's single-workgroup partition
+    (shaders-sdk/radix/partition.comp:29-68), 2 and 5 scan groups."""
     import torch
     import radx_amd
     keys = make_keys("hash", n, 4, seed=11)
@@ -106,7 +110,7 @@ def test_u32_every_pass_matches_oracle(device, n, fused):
 
 
 @pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("n", [777, 2048, 5 * 2048 + 9, 9 * 2048 + 1])
+@pytest.mark.parametrize("n", [777, 2048, 5 * 2048 + 9, 9 * 2048 + 1, 300 * 2048 + 5])
 def test_u64_kv_every_pass_matches_oracle(device, n, fused):
     import torch
     import radx_amd
@@ -275,9 +279,10 @@ def test_medium_2_24_vs_cpu(device):
     assert np.array_equal(got, oracle.parallel_sort(keys))
 
 
-def test_full_size_2_28_properties(device):
-    """The 2^28-key uint32 benchmark configuration through size-independent properties: sortedness and a
-    preserved multiset checksum; plus exact equality on a strided sample against numpy."""
+def test_config2_2_28_properties_and_full_equality(device):
+    """The 2^28-key uint32 benchmark configuration: sortedness and a preserved multiset checksum
+    (the size-independent properties), then the whole array bit for bit against the CPU sort of
+    the same generated keys."""
     import torch
     import radx_amd
     n = 1 << 28
@@ -291,6 +296,8 @@ def test_full_size_2_28_properties(device):
     assert radx_amd.check_sorted(k) == 0
     assert radx_amd.checksum(k) == before
     s.close()
+    want = oracle.parallel_sort(oracle.generate_u32(n, 7))
+    assert np.array_equal(to_host(k), want)
 
 
 def ordered_image(keys, kind, descending):
@@ -417,13 +424,15 @@ def test_config3_2_30_full_equality_vs_cpu(device):
     s.close()
 
 
-def test_config4_2_28_u64_kv_properties(device):
-    """The key-value benchmark shape (uint64 key + uint32 payload = original index) at 2^28 pairs:
-    keys sorted, payloads strictly increasing within equal-key runs (stability), every output key
-    equals the input key its payload points to, and the key multiset checksum is preserved."""
+@pytest.mark.parametrize("log2n", [28, 30])
+def test_config4_u64_kv_properties(device, log2n):
+    """The key-value benchmark configuration (uint64 key + uint32 payload = original index) at 2^28
+    and at its full 2^30 pairs: keys sorted, payloads strictly increasing within equal-key runs
+    (stability), every output key equals the input key its payload points to, and the key
+    multiset checksum is preserved."""
     import torch
     import radx_amd
-    n = 1 << 28
+    n = 1 << log2n
     k = torch.empty(n, dtype=torch.int64, device=device)
     v = torch.empty(n, dtype=torch.int32, device=device)
     radx_amd.generate_u64(k, v, seed=9)
@@ -437,6 +446,8 @@ def test_config4_2_28_u64_kv_properties(device):
     assert radx_amd.checksum(k) == before
     assert bool((orig[v.long()] == k).all().item())  # keys_in[payload[i]] == keys_out[i]
     s.close()
+    del k, v, orig
+    torch.cuda.empty_cache()
 
 
 def test_sort_is_graph_capturable(device):
