@@ -79,6 +79,23 @@ int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals,
                   void* vals_swap, uint64_t n, void* stream);
 
 /*
+ * radx_hip_sort without a sorter handle and without any allocation.  It has no counterpart in
+ * the reference (whose scratch is always a buffer allocated by Radix::createInternalMemory); it is
+ * for callers that cannot call hipMalloc — code under HIP graph capture, tight serving loops,
+ * harnesses that forbid allocation.  The histogram / prefix-scan tables live in a fixed device
+ * array inside the library's code object (about 6 MiB, resident on every GPU the library is loaded
+ * on until the process ends), so n is limited to RADX_HIP_NOALLOC_MAX_N elements; larger n fails
+ * with hipErrorInvalidValue and a message.  Unsigned ascending order; key_bytes 4 or 8,
+ * value_bytes 0 or 4, buffers as for radx_hip_sort.  The call makes no hipMalloc / hipFree and
+ * enqueues the same kernels as radx_hip_sort on `stream`.  All calls on one GPU share that GPU's
+ * array: calls that overlap in time on the same GPU (two streams, two threads) race on it, so
+ * serialise them (one stream, or events between streams).  Nothing carries over between calls.
+ */
+#define RADX_HIP_NOALLOC_MAX_N (1ull << 26)
+int radx_hip_sort_noalloc(int device, void* keys, void* keys_swap, void* vals, void* vals_swap,
+                          uint64_t n, int key_bytes, int value_bytes, void* stream);
+
+/*
  * As radx_hip_sort, restricted to key bits [begin_bit, end_bit).  The number of passes,
  * ceil((end_bit-begin_bit)/4), is rounded up to an even count so the result still lands
  * in `keys`; a padding pass sorts on a zero-width digit and is a stable copy.

@@ -6,6 +6,6 @@ This package is the Python driver the tests and bench.py use to reach that C ABI
 """
 from .capi import LIB_PATH, RadxError, lib  # noqa: F401  (import loads the .so or raises)
 from .sorter import (Sorter, check_sorted, checksum, generate_u32, generate_u64,  # noqa: F401
-                     indiction, permutation)
+                     indiction, permutation, sort_noalloc)
 
-__all__ = ["Sorter", "RadxError", "generate_u32", "generate_u64", "check_sorted", "checksum", "indiction", "permutation", "lib", "LIB_PATH"]
+__all__ = ["Sorter", "RadxError", "generate_u32", "generate_u64", "check_sorted", "checksum", "indiction", "permutation", "sort_noalloc", "lib", "LIB_PATH"]

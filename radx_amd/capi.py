@@ -22,6 +22,8 @@ SIGNATURES = {
                                        ctypes.POINTER(_vp)]),
     "radx_hip_destroy": (ctypes.c_int, [_vp]),
     "radx_hip_sort": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, _vp]),
+    "radx_hip_sort_noalloc": (ctypes.c_int, [ctypes.c_int, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,
+                                             ctypes.c_int, _vp]),
     "radx_hip_sort_bits": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,
                                           ctypes.c_int, _vp]),
     "radx_hip_sort_bits_into": (ctypes.c_int, [_vp, _vp, _vp, _vp, _vp, ctypes.c_uint64, ctypes.c_int,
@@ -45,6 +47,9 @@ SIGNATURES = {
     "radx_hip_check_sorted": (ctypes.c_int, [_vp, _vp, ctypes.c_uint64, ctypes.c_int, _u64p, _vp]),
     "radx_hip_checksum": (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.c_int, _u64p, _vp]),
 }
+
+
+NOALLOC_MAX_N = 1 << 26  # RADX_HIP_NOALLOC_MAX_N
 
 
 class RadxError(RuntimeError):

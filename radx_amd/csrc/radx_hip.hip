@@ -34,6 +34,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -1202,6 +1203,83 @@ int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, v
                   uint64_t n, void* stream) {
     if (!s) return bad_arg("sorter is NULL");
     return radx_hip_sort_bits(s, keys, keys_swap, vals, vals_swap, n, 0, s->key_bytes * 8, stream);
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// The sort for callers that cannot allocate (code under HIP graph capture, serving loops and
+// harnesses that forbid hipMalloc): the same pass loop as radx_hip_sort with the tables in a
+// device array that is part of the code object instead of a sorter's hipMalloc'ed scratch.
+//
+// Every GPU the library runs on holds its own copy of the array (sized for the largest input the
+// entry point accepts) at its own address, from module load until the process ends.  In host code
+// the array's name is only a handle for hipGetSymbolAddress — it is not a device address and must
+// never be handed to a kernel or a memset.  The address is looked up once per device, with that
+// device current, and every use goes through the looked-up pointer.
+//
+// All calls on one GPU share that GPU's array and the array keeps the last call's contents.
+// Nothing in it has to be cleared by the caller: the histogram kernel stores every table row the
+// scan later reads, the scan zeroes the accumulation table in front of every scatter, and it
+// rewrites the run starts.  Two calls that overlap in time on one GPU race on the tables.
+// ---------------------------------------------------------------------------------------------
+namespace {
+constexpr uint64_t kNoAllocMaxN = RADX_HIP_NOALLOC_MAX_N;
+constexpr size_t kNoAllocScratchBytes = layout_for(kNoAllocMaxN, 8).total;  // 8-byte keys have the smaller tile: more rows
+static_assert(layout_for(kNoAllocMaxN, 4).total <= kNoAllocScratchBytes, "the 4-byte-key layout must fit as well");
+static_assert(kNoAllocScratchBytes <= (8u << 20), "keep the resident array modest");
+constexpr int kMaxDevices = 64;
+}  // namespace
+
+static __device__ __align__(256) unsigned char scratch[kNoAllocScratchBytes];
+
+namespace {
+std::mutex g_scratch_mutex;
+char* g_scratch_ptr[kMaxDevices] = {};  // per device: where that device's copy of `scratch` lives
+
+// Address of `device`'s copy of the array; looked up on first use, with that device current.
+int static_scratch_of(int device, char** out) {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device]) {
+        void* ptr = nullptr;
+        RADX_TRY(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (!ptr) return fail(hipErrorInvalidSymbol, "hipGetSymbolAddress(scratch) returned NULL");
+        g_scratch_ptr[device] = static_cast<char*>(ptr);
+    }
+    *out = g_scratch_ptr[device];
+    return 0;
+}
+}  // namespace
+
+extern "C" {
+
+int radx_hip_sort_noalloc(int device, void* keys, void* keys_swap, void* vals, void* vals_swap, uint64_t n,
+                          int key_bytes, int value_bytes, void* stream) {
+    if (key_bytes != 4 && key_bytes != 8) return bad_arg("key_bytes must be 4 or 8");
+    if (value_bytes != 0 && value_bytes != 4) return bad_arg("value_bytes must be 0 or 4");
+    if (device < 0 || device >= kMaxDevices) return bad_arg("device must be 0..63");
+    if (n > kNoAllocMaxN) {
+        snprintf(g_error, sizeof(g_error),
+                 "invalid argument: radx_hip_sort_noalloc sorts at most %llu elements (its tables live in a fixed "
+                 "%zu-byte device array); use a sorter from radx_hip_create for %llu",
+                 static_cast<unsigned long long>(kNoAllocMaxN), kNoAllocScratchBytes, static_cast<unsigned long long>(n));
+        return static_cast<int>(hipErrorInvalidValue);
+    }
+    radx_hip_sorter s;  // on the stack; with profiling off its (empty) vectors never allocate
+    s.device = device;
+    s.max_n = kNoAllocMaxN;
+    s.key_bytes = key_bytes;
+    s.value_bytes = value_bytes;
+    if (const int rc = check_buffers(&s, keys, keys_swap, vals, vals_swap, n)) return rc;
+    if (n == 0) return 0;
+    DeviceGuard guard(device);
+    RADX_TRY(guard.status());
+    char* base = nullptr;
+    if (const int rc = static_scratch_of(device, &base)) return rc;
+    s.layout = layout_for(n, key_bytes);  // tables sized for this call: always within the array
+    bind_scratch(&s, base);
+    return sort_bits_impl(&s, keys, keys_swap, vals, vals_swap, n, 0, key_bytes * 8, nullptr, nullptr,
+                          static_cast<hipStream_t>(stream));
 }
 
 int radx_hip_geometry(const radx_hip_sorter* s, uint64_t n, uint32_t* tile_keys, uint32_t* num_tiles) {

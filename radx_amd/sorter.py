@@ -148,6 +148,19 @@ class Sorter:
         return {k: (ms[i], int(cnt[i])) for i, k in enumerate(("hist", "scan", "scatter"))}
 
 
+def sort_noalloc(keys, swap, vals=None, vals_swap=None, n=None, stream=None):
+    """Full sort through radx_hip_sort_noalloc: no sorter handle, no allocation, tables in the
+    library's resident device array; n <= capi.NOALLOC_MAX_N.  Calls on one GPU must not overlap."""
+    n = keys.numel() if n is None else int(n)
+    for t, name in ((keys, "keys"), (swap, "swap"), (vals, "vals"), (vals_swap, "vals_swap")):
+        if t is not None and (not t.is_cuda or not t.is_contiguous() or t.numel() < n):
+            raise ValueError("%s must be a contiguous device tensor of at least n elements" % name)
+    device = keys.device.index if keys.device.index is not None else 0
+    capi.check(capi.lib.radx_hip_sort_noalloc(device, _ptr(keys), _ptr(swap), _ptr(vals), _ptr(vals_swap), n,
+                                              keys.element_size(), 0 if vals is None else 4,
+                                              _stream(stream, keys.device)))
+
+
 def generate_u32(keys, seed, n=None, stream=None):
     n = keys.numel() if n is None else int(n)
     capi.check(capi.lib.radx_hip_generate_u32(_ptr(keys), n, seed & 0xFFFFFFFF,
