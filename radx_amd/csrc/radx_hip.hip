@@ -401,7 +401,7 @@ template <typename K, bool HAS_V, bool FUSE>
 __global__ __launch_bounds__(kBlock) void scatter_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* __restrict__ vin,
     uint32_t* __restrict__ vout, uint32_t n, int bit, uint32_t mask,
-    const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ group_sums,
+    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ group_sums,
     uint32_t num_tiles, int next_bit, uint32_t next_mask, uint32_t* __restrict__ next_counts,
     int order_in, int order_out) {
     constexpr int KPT = KeyTraits<K>::kpt;
@@ -410,11 +410,29 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     constexpr int PER_VEC = 16 / sizeof(K);
     constexpr int NVEC = kThreadDwords / 4;
     constexpr int KEY_DWORDS = sizeof(K) / 4;
+#if defined(RADX_EXP_ALIGN_ALL)
+    constexpr bool ALIGNED = true;
+#elif defined(RADX_EXP_ALIGN_NONE)
+    constexpr bool ALIGNED = false;
+#else
+    constexpr bool ALIGNED = sizeof(K) == 8;
+#endif
+    // ALIGNED: the rank-ordered LDS array has up to ALIGN_E - 1 empty slots in front of every
+    // digit's run, chosen so that slot number and global output index agree modulo ALIGN_E
+    // (128 bytes of keys).  A wave of the store loop covers 64 consecutive slots starting at a
+    // multiple of 64, so every store instruction writes whole 128-byte lines except at the two
+    // ends of a run.
+    constexpr uint32_t ALIGN_E = ALIGNED ? 128u / sizeof(K) : 1u;
+    constexpr uint32_t SLOTS = ALIGNED ? (TILE + kRadices * (ALIGN_E - 1u) + kBlock - 1u) / kBlock * kBlock : TILE;
+    constexpr int NIT = SLOTS / kBlock;  // store-loop iterations: 16 -> 18 (4-byte keys), 8 -> 9 (8-byte keys)
 
-    __shared__ __attribute__((aligned(16))) uint32_t stage[kTileDwords];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[SLOTS * KEY_DWORDS];
     __shared__ __attribute__((aligned(16))) uint32_t ctr[kCtrRows * kBlock];  // FUSE: reused as next_first[64][32]
     __shared__ uint32_t next_second[FUSE ? kRadices * kRadices : 1];
-    __shared__ __attribute__((aligned(8))) uint2 where_s[kRadices];  // .x = global base - tile start of the digit, .y = last index of its first destination tile
+    // per digit: .x = global base - first slot of the digit, .y = last index of its first destination
+    // tile, .z = first slot, .w = number of keys (ALIGNED only)
+    __shared__ __attribute__((aligned(16))) uint4 where_s[kRadices];
+    __shared__ uint32_t padpack_s[ALIGNED ? kCtrRows : 1];  // empty slots in front of digits r (low half) and r + 8 (high half)
     __shared__ uint32_t wave_tot[kBlock / 64];
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
@@ -423,10 +441,12 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     const uint32_t valid = min(TILE, n - base);
 
     // Global output base of every digit for this tile; issued first, consumed after the scan.
-    uint32_t run_base = 0;
-    if (tid < static_cast<uint32_t>(kRadices))
+    uint32_t run_base = 0, run_len = 0;
+    if (tid < static_cast<uint32_t>(kRadices)) {
         run_base = offsets[static_cast<size_t>(g) * kRadices + tid] +
                    group_sums[static_cast<size_t>(tid) * ((num_tiles + kScanBlocks - 1) / kScanBlocks) + g / kScanBlocks];
+        if (ALIGNED) run_len = counts[static_cast<size_t>(g) * kRadices + tid];
+    }
 
     K key[KPT];
     uint32_t val[HAS_V ? KPT : 1];
@@ -436,12 +456,26 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
 #pragma unroll
         for (int m = 0; m < NVEC; ++m) v[m] = stream_load4(&src[m * kBlock + tid]);
         if (HAS_V) {
+            // Payloads are loaded the way the keys are — consecutive lanes, consecutive 16 bytes —
+            // and handed to their owning threads through an LDS image of KPT dwords per row.
+            constexpr uint32_t C = KPT / 4;  // 16-byte chunks per row
+            uint32_t* vimg = stage;
             const uint4* vsrc = reinterpret_cast<const uint4*>(vin + base);
+            uint4 q[C];
 #pragma unroll
-            for (int j = 0; j < KPT / 4; ++j) {
-                const uint4 q = stream_load4(&vsrc[tid * (KPT / 4) + j]);
-                val[4 * j + 0] = q.x; val[4 * j + 1] = q.y; val[4 * j + 2] = q.z; val[4 * j + 3] = q.w;
+            for (uint32_t j = 0; j < C; ++j) q[j] = stream_load4(&vsrc[j * kBlock + tid]);
+#pragma unroll
+            for (uint32_t j = 0; j < C; ++j) {
+                const uint32_t idx = j * kBlock + tid, row = idx / C, chunk = idx % C;
+                *reinterpret_cast<uint4*>(&vimg[row * KPT + (((chunk ^ (row >> 2)) & (C - 1u)) << 2)]) = q[j];
             }
+            __syncthreads();
+#pragma unroll
+            for (uint32_t j = 0; j < C; ++j) {
+                const uint4 r = *reinterpret_cast<const uint4*>(&vimg[tid * KPT + (((j ^ (tid >> 2)) & (C - 1u)) << 2)]);
+                val[4 * j + 0] = r.x; val[4 * j + 1] = r.y; val[4 * j + 2] = r.z; val[4 * j + 3] = r.w;
+            }
+            __syncthreads();  // the key image goes into the same words
         }
 #pragma unroll
         for (int m = 0; m < NVEC; ++m) {
@@ -461,6 +495,26 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         if (HAS_V) {
 #pragma unroll
             for (int i = 0; i < KPT; ++i) val[i] = vin[base + min(tid * KPT + i, valid - 1u)];
+        }
+    }
+    if (ALIGNED && wave == 0u) {
+        // Lanes 0..15 hold digit d's key count and global output base.  The digit's first slot
+        // is its tile rank start plus a pad that makes slot = output index (mod ALIGN_E); pads
+        // must not decrease from digit to digit, hence the 16-step recurrence.
+        const uint32_t start = wave_inclusive_scan(run_len) - run_len;
+        const uint32_t want = (run_base - start) & (ALIGN_E - 1u);
+        uint32_t pad = 0, prev = 0;
+#pragma unroll
+        for (int d = 0; d < kRadices; ++d) {
+            const uint32_t mine = prev + ((want - prev) & (ALIGN_E - 1u));
+            if (lane == static_cast<uint32_t>(d)) pad = mine;
+            prev = __builtin_amdgcn_readlane(mine, d);
+        }
+        const uint32_t hi = __shfl_down(pad, 8, 64);
+        if (tid < static_cast<uint32_t>(kRadices)) {
+            const uint32_t first = start + pad;
+            where_s[tid] = make_uint4(run_base - first, run_base | (TILE - 1u), first, run_len);
+            if (tid < static_cast<uint32_t>(kCtrRows)) padpack_s[tid] = pad | (hi << 16);
         }
     }
     __syncthreads();
@@ -516,6 +570,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         }
         // digits 8..15 (high halves) sort after all of digits 0..7 (low halves)
         uint32_t run = incl - total + before + ((all & 0xffffu) << 16);
+        if (ALIGNED) run += padpack_s[tid >> 5];  // thread t owns words 8t..8t+7: counter row t / 32
         uint32_t o[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) { o[i] = run; run += c[i]; }
@@ -533,9 +588,9 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         if (PACK) rank[i / 2] += before << ((i & 1) << 4);  // stays below the tile size: no carry into the other half
         else rank[i] += before;
     }
-    if (tid < static_cast<uint32_t>(kRadices)) {
+    if (!ALIGNED && tid < static_cast<uint32_t>(kRadices)) {
         const uint32_t start = (ctr[(tid & 7u) * kBlock] >> ((tid >> 3) << 4)) & 0xffffu;
-        where_s[tid] = make_uint2(run_base - start, run_base | (TILE - 1u));
+        where_s[tid] = make_uint4(run_base - start, run_base | (TILE - 1u), 0u, 0u);
     }
     if (FUSE) {
         // The rank counters are dead once read: every thread clears the column only it read
@@ -556,17 +611,18 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     // back instead of one read -> wait -> read -> wait -> store chain per key.  Measured at 2^30:
     // uint32 keys 13.45 -> 13.05 ms per sort with groups of 4..16; uint64 + payload 84.5 -> 83.2 ms
     // with 8; uint64 keys alone are fastest one at a time.
-    constexpr int kGroup = (sizeof(K) == 8 && !HAS_V) ? 1 : 8;
+    constexpr int kGroup = ALIGNED ? (sizeof(K) == 4 ? 6 : (HAS_V ? 3 : 1)) : (sizeof(K) == 8 && !HAS_V) ? 1 : 8;
+    static_assert(NIT % kGroup == 0, "the store loop handles whole groups");
     const uint32_t col = tid & 31u;
     // rank_slot(m * 256 + tid) = rank_slot((m & 3) * 256 + tid) + (m >> 2) * 1024: the XOR only
     // sees index bits 5..9 and only changes bits 0..4, so four bases serve all the reads.
     uint32_t read_base[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) read_base[q] = rank_slot<sizeof(K)>(q * kBlock + tid);
-    uint32_t where[HAS_V ? KPT : 1];
+    uint32_t where[HAS_V ? NIT : 1];
     auto emit = [&](int m0, bool guarded, int restore) {
         K k[kGroup];
-        uint2 w[kGroup];
+        uint4 w[kGroup];
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) k[j] = skeys[read_base[(m0 + j) & 3] + ((m0 + j) >> 2) * (4 * kBlock)];
 #pragma unroll
@@ -576,8 +632,10 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         for (int j = 0; j < kGroup; ++j) {
             const uint32_t s = (m0 + j) * kBlock + tid;
             const uint32_t at = w[j].x + s;
-            if (HAS_V) where[m0 + j] = at;
-            const bool live = !guarded || s < valid;
+            // ALIGNED: a slot holds a key of digit d only inside d's run of slots; what the empty
+            // slots hold (stale words) never passes this test, whatever digit it decodes to
+            const bool live = ALIGNED ? (s - w[j].z) < w[j].w : (!guarded || s < valid);
+            if (HAS_V) where[m0 + j] = ALIGNED && !live ? 0xffffffffu : at;
             if (live) kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];  // last pass restores the key's own bits
             if (FUSE) {
                 const uint32_t slot = (digit_of<K>(k[j], bit, mask) << 4) | digit_of<K>(k[j], next_bit, next_mask);
@@ -614,10 +672,10 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     };
     if (valid == TILE && order_out == 0) {
 #pragma unroll
-        for (int m = 0; m < KPT; m += kGroup) emit(m, false, 0);
+        for (int m = 0; m < NIT; m += kGroup) emit(m, false, 0);
     } else {
 #pragma unroll
-        for (int m = 0; m < KPT; m += kGroup) emit(m, true, order_out);
+        for (int m = 0; m < NIT; m += kGroup) emit(m, true, order_out);
     }
 
     if (FUSE) {
@@ -648,9 +706,10 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         for (int i = 0; i < KPT; ++i) stage[rank_slot<4>(rank_of(i))] = val[i];
         __syncthreads();
 #pragma unroll
-        for (int m = 0; m < KPT; ++m) {
+        for (int m = 0; m < NIT; ++m) {
             const uint32_t s = m * kBlock + tid;
-            if (s < valid) vout[where[m]] = stage[rank_slot<4>((m & 3) * kBlock + tid) + (m >> 2) * (4 * kBlock)];
+            if (ALIGNED ? where[m] != 0xffffffffu : s < valid)
+                vout[where[m]] = stage[rank_slot<4>((m & 3) * kBlock + tid) + (m >> 2) * (4 * kBlock)];
         }
     }
 }
@@ -956,11 +1015,11 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
         LaunchTimer t(s, 2, stream);
         if (a.fuse_next)
             hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true>), dim3(g.num_tiles), dim3(kBlock), 0, stream,
-                               kin, kout, vin, vout, a.n, a.bit, mask, s->offsets, s->group_sums, g.num_tiles,
+                               kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
                                a.next_bit, next_mask, next_counts, a.order_in, a.order_out);
         else
             hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false>), dim3(g.num_tiles), dim3(kBlock), 0, stream,
-                               kin, kout, vin, vout, a.n, a.bit, mask, s->offsets, s->group_sums, g.num_tiles,
+                               kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
                                0, 0u, static_cast<uint32_t*>(nullptr), a.order_in, a.order_out);
     }
     RADX_TRY(hipGetLastError());

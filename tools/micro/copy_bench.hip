@@ -83,6 +83,69 @@ template <bool NT_ST> __global__ __launch_bounds__(256) void copy_runs_nt(const 
         if (NT_ST) __builtin_nontemporal_store(l[m * 256 + threadIdx.x], &out[where]); else out[where] = l[m * 256 + threadIdx.x];
     }
 }
+// dwordx4 loads, LDS staging, dword stores, T threads per workgroup and 16 dwords per thread
+template <int T> __global__ __launch_bounds__(T) void copy_staged(const uint4* in, uint32_t* out, uint32_t blocks) {
+    __shared__ uint4 lds[T * 4];
+    const uint32_t t = remap(blockIdx.x, blocks);
+    const uint4* s = in + (size_t)t * T * 4; uint32_t* d = out + (size_t)t * T * 16;
+    for (int m = 0; m < 4; ++m) lds[m * T + threadIdx.x] = nt_load4(&s[m * T + threadIdx.x]);
+    __syncthreads();
+    const uint32_t* l = (const uint32_t*)lds;
+    for (int m = 0; m < 16; ++m) d[m * T + threadIdx.x] = l[m * T + threadIdx.x];
+}
+// two adjacent tiles per 256-thread workgroup, second tile's loads issued before the first is stored
+__global__ __launch_bounds__(256) void copy_two(const uint4* in, uint32_t* out, uint32_t tiles) {
+    __shared__ uint4 lds[1024];
+    const uint32_t t = remap(blockIdx.x, tiles / 2) * 2;
+    const uint4* s = in + (size_t)t * 1024; uint32_t* d = out + (size_t)t * 4096;
+    uint4 a[4], b[4];
+    for (int m = 0; m < 4; ++m) a[m] = nt_load4(&s[m * 256 + threadIdx.x]);
+    for (int m = 0; m < 4; ++m) b[m] = nt_load4(&s[1024 + m * 256 + threadIdx.x]);
+    const uint32_t* l = (const uint32_t*)lds;
+    for (int m = 0; m < 4; ++m) lds[m * 256 + threadIdx.x] = a[m];
+    __syncthreads();
+    for (int m = 0; m < 16; ++m) d[m * 256 + threadIdx.x] = l[m * 256 + threadIdx.x];
+    __syncthreads();
+    for (int m = 0; m < 4; ++m) lds[m * 256 + threadIdx.x] = b[m];
+    __syncthreads();
+    for (int m = 0; m < 16; ++m) d[4096 + m * 256 + threadIdx.x] = l[m * 256 + threadIdx.x];
+}
+// The 16-run store shape again, but every wave instruction writes one 256-byte-aligned window of the
+// destination: run r is laid out in a slot space of 320 slots at offset (destination start mod 64),
+// so slot windows of 64 coincide with aligned destination windows; lanes outside the run are idle.
+__global__ __launch_bounds__(256) void copy_runs_aligned(const uint4* in, uint32_t* out, uint32_t tiles, uint32_t shift) {
+    __shared__ uint4 lds[1024];
+    const uint32_t t = remap(blockIdx.x, tiles);
+    const uint4* s = in + (size_t)t * 1024;
+    for (int m = 0; m < 4; ++m) lds[m * 256 + threadIdx.x] = nt_load4(&s[m * 256 + threadIdx.x]);
+    __syncthreads();
+    const uint32_t* l = (const uint32_t*)lds;
+    const size_t region = (size_t)tiles * 256;
+    for (int it = 0; it < 20; ++it) {
+        const uint32_t p = it * 256 + threadIdx.x, r = p / 320, q = p % 320;
+        size_t start = (size_t)r * region + (size_t)t * 256 + shift + r * 7 + (size_t)r * 790528;  // every region its own misalignment; region starts not a power of two apart
+        const uint32_t pad = (uint32_t)(start & 63);
+        if (q >= pad && q < pad + 256) {
+            size_t where = start - pad + q;
+            if (where >= (size_t)tiles * 4096) where -= (size_t)tiles * 4096;
+            out[where] = l[r * 256 + q - pad];
+        }
+    }
+}
+__global__ __launch_bounds__(256) void copy_runs_misaligned(const uint4* in, uint32_t* out, uint32_t tiles, uint32_t shift) {
+    __shared__ uint4 lds[1024];
+    const uint32_t t = remap(blockIdx.x, tiles);
+    const uint4* s = in + (size_t)t * 1024;
+    for (int m = 0; m < 4; ++m) lds[m * 256 + threadIdx.x] = nt_load4(&s[m * 256 + threadIdx.x]);
+    __syncthreads();
+    const uint32_t* l = (const uint32_t*)lds;
+    const size_t region = (size_t)tiles * 256;
+    for (int r = 0; r < 16; ++r) {
+        size_t where = (size_t)r * region + (size_t)t * 256 + shift + r * 7 + (size_t)r * 790528 + threadIdx.x;
+        if (where >= (size_t)tiles * 4096) where -= (size_t)tiles * 4096;
+        out[where] = l[r * 256 + threadIdx.x];
+    }
+}
 int main(int argc, char** argv) {
     const size_t n = (size_t)1 << (argc > 1 ? atoi(argv[1]) : 30); const uint32_t tiles = n / 4096;
     uint32_t *a, *b; CK(hipMalloc(&a, n * 4)); CK(hipMalloc(&b, n * 4));
@@ -109,6 +172,14 @@ int main(int argc, char** argv) {
     run("1024-thread blocks", [&] { copy_big<1024><<<tiles / 4, 1024>>>((uint4*)a, (uint4*)b, tiles / 4); });
     run("runs shift13 nt-load", [&] { copy_runs_nt<false><<<tiles, 256>>>((uint4*)a, b, tiles, 13); });
     run("runs shift13 nt-load+store", [&] { copy_runs_nt<true><<<tiles, 256>>>((uint4*)a, b, tiles, 13); });
+    run("staged 256 threads", [&] { copy_staged<256><<<tiles, 256>>>((uint4*)a, b, tiles); });
+    run("staged 512 threads", [&] { copy_staged<512><<<tiles / 2, 512>>>((uint4*)a, b, tiles / 2); });
+    run("staged 1024 threads", [&] { copy_staged<1024><<<tiles / 4, 1024>>>((uint4*)a, b, tiles / 4); });
+    run("two tiles per 256-thread wg", [&] { copy_two<<<tiles / 2, 256>>>((uint4*)a, b, tiles); });
+    run("16 runs misaligned (r*7+13)", [&] { copy_runs_misaligned<<<tiles, 256>>>((uint4*)a, b, tiles, 13); });
+    run("16 runs, aligned windows", [&] { copy_runs_aligned<<<tiles, 256>>>((uint4*)a, b, tiles, 13); });
+    run("16 runs misaligned (r*7+0)", [&] { copy_runs_misaligned<<<tiles, 256>>>((uint4*)a, b, tiles, 0); });
+    run("16 runs, aligned windows +0", [&] { copy_runs_aligned<<<tiles, 256>>>((uint4*)a, b, tiles, 0); });
     run("hipMemcpyDtoD", [&] { hipMemcpyAsync(b, a, n * 4, hipMemcpyDeviceToDevice, 0); });
     return 0;
 }
