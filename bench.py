@@ -157,7 +157,14 @@ def other_configs(dev):
                 radx_amd.generate_u64(k, vals[i], seed=1000 + i)
         s = radx_amd.Sorter(n, kb, vb)
         before = radx_amd.checksum(keys[steps])  # multiset of the last timed batch, before its sort
-        s.sort(keys[0], swap, vals[0] if vb else None, vswap)
+        # warm-up: a few sorts of a scratch batch (regenerated each time), at least ~50 ms of work,
+        # so the timed sorts do not include the clock ramp after the idle gap of the set-up above
+        for w in range(3 if log2n >= 30 else 16):
+            if kb == 4:
+                radx_amd.generate_u32(keys[0], seed=500 + w)
+            else:
+                radx_amd.generate_u64(keys[0], vals[0], seed=500 + w)
+            s.sort(keys[0], swap, vals[0] if vb else None, vswap)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(1, steps + 1):
