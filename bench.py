@@ -44,6 +44,11 @@ def parse():
     ap.add_argument("--rehearse-exchange", action="store_true",
                     help="on one GPU, run the N > 1 code path (RCCL process group of one rank, split + "
                          "16 all-to-all-v's + per-region local passes) instead of the plain sort")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend of the N > 1 path (nccl = RCCL; gloo only to rehearse the "
+                         "multi-rank code on a box whose ranks must share one GPU)")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal only: every rank uses GPU 0 (needs --backend gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--print-launch", action="store_true",
                     help="with --gpus N > 1 and no WORLD_SIZE in the environment: print the child "
                          "commands and rank environments as JSON instead of starting them")
@@ -227,19 +232,26 @@ def main():
     import torch
     import torch.distributed as dist
     import radx_amd
-    from radx_amd.sharded import HipEngine, ShardedSorter, init_process_group
+    from radx_amd.sharded import HipEngine, HostStagedCollectives, ShardedSorter, init_process_group
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     args.gpus = world  # the launcher (ours or torch.distributed.run) decides the number of ranks
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     multi = world > 1 or args.rehearse_exchange  # the split / exchange / per-region path
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        init_process_group(dev, rank=rank, world_size=world)
+        if args.backend == "nccl":
+            init_process_group(dev, rank=rank, world_size=world)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    # the collectives of the N > 1 path: RCCL on device tensors, or (rehearsal) gloo through host copies
+    coll = dist if args.backend == "nccl" else HostStagedCollectives(dist)
 
     n = 1 << args.log2n
     K, W = args.steps, args.warmup
@@ -260,7 +272,7 @@ def main():
     for i in range(pool_n):
         fill(i, i)
     engine = HipEngine(cap, 4, local_rank)
-    sharder = ShardedSorter(engine, exchange_when_alone=True) if multi else None
+    sharder = ShardedSorter(engine, exchange_when_alone=True, dist=coll) if multi else None
     checks = radx_amd.checksum(pool[(K + W - 1) % pool_n], n=n)  # of the last timed step's input
 
     def step(i):
@@ -272,7 +284,7 @@ def main():
     def fence():
         torch.cuda.synchronize()
         if multi:
-            dist.barrier()
+            coll.barrier()
             torch.cuda.synchronize()
 
     for w in range(W):
@@ -304,7 +316,7 @@ def main():
         timing = "per-step HIP events (batch pool of %d regenerated between steps)" % pool_n
     if multi:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        coll.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
     # correctness of the last timed step, outside the timed region
@@ -321,7 +333,7 @@ def main():
             return v - (1 << 64) if v >= (1 << 63) else v
         sums = torch.tensor([wrap(checks[0]), wrap(checks[2]), wrap(after[0]), wrap(after[2])],
                             dtype=torch.int64, device=dev)
-        dist.all_reduce(sums)
+        coll.all_reduce(sums)
         sums = sums.tolist()
         verified = verified and sums[0] == sums[2] and sums[1] == sums[3]
         b = world.bit_length() - 1
@@ -329,10 +341,10 @@ def main():
         if top is not None:
             verified = verified and bool((top == rank).all().item())
         tot = torch.tensor([last_len], dtype=torch.int64, device=dev)
-        dist.all_reduce(tot)
+        coll.all_reduce(tot)
         verified = verified and int(tot.item()) == n * world
         v = torch.tensor([1 if verified else 0], device=dev)
-        dist.all_reduce(v, op=dist.ReduceOp.MIN)
+        coll.all_reduce(v, op=dist.ReduceOp.MIN)
         verified = bool(v.item())
 
     # Per-launch kernel times, outside the timed region: the same steps again on freshly generated
@@ -408,8 +420,9 @@ def main():
         if multi:
             # xGMI traffic of one step, reported beside the HBM figures (never part of them)
             out["exchange"] = {"bytes_sent_per_gpu": round(4.0 * n * (world - 1) / world),
-                               "all_to_all_calls_per_step": 16 // world, "backend": "nccl (RCCL)",
-                               "overlapped_with_local_passes": True,
+                               "all_to_all_calls_per_step": 16 // world,
+                               "backend": "nccl (RCCL)" if args.backend == "nccl" else "gloo (rehearsal)",
+                               "overlapped_with_local_passes": args.backend == "nccl",
                                "last_step_timeline_ms_rank0": timeline}
         if extras is not None:
             out["other_configs"] = extras
@@ -424,7 +437,7 @@ def main():
 
     engine.close()
     if multi:
-        dist.barrier()
+        coll.barrier()
         dist.destroy_process_group()
 
 

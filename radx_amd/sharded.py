@@ -44,6 +44,51 @@ def init_process_group(device, **kwargs):
     dist.init_process_group("nccl", device_id=device, **kwargs)
 
 
+class HostStagedCollectives:
+    """torch.distributed's collectives for device tensors over a backend that only moves host
+    memory (gloo): every call copies its input to the host, runs the collective there and copies
+    the result back, synchronously.  Lets the multi-rank path be rehearsed on a box whose ranks
+    must share one GPU (RCCL refuses two ranks on one device); never used with RCCL."""
+
+    class Done:
+        def wait(self):
+            return True
+
+    def __init__(self, dist=None):
+        if dist is None:
+            import torch.distributed as dist
+        self.dist = dist
+
+    def get_world_size(self, group=None):
+        return self.dist.get_world_size(group)
+
+    def get_rank(self, group=None):
+        return self.dist.get_rank(group)
+
+    def barrier(self, group=None):
+        self.dist.barrier(group=group)
+
+    def all_gather_into_tensor(self, out, mine, group=None):
+        host = out.cpu()
+        self.dist.all_gather_into_tensor(host, mine.cpu(), group=group)
+        out.copy_(host)
+
+    def all_reduce(self, t, op=None, group=None):
+        host = t.cpu()
+        if op is None:
+            self.dist.all_reduce(host, group=group)
+        else:
+            self.dist.all_reduce(host, op=op, group=group)
+        t.copy_(host)
+
+    def all_to_all_single(self, out, inp, output_split_sizes, input_split_sizes, group=None, async_op=False):
+        host = out.cpu()
+        self.dist.all_to_all_single(host, inp.cpu(), output_split_sizes=output_split_sizes,
+                                    input_split_sizes=input_split_sizes, group=group)
+        out.copy_(host)
+        return self.Done()
+
+
 class HipEngine:
     """split / local sort through libradx_hip.so on one device."""
 
