@@ -18,6 +18,7 @@ generated batches collects the per-launch kernel times behind `roofline`.
 """
 import argparse
 import ctypes
+import datetime
 import hashlib
 import json
 import os
@@ -246,10 +247,13 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
+        # a collective that does not complete within 4 minutes aborts the rank (and, through the
+        # launcher, the run) instead of hanging the whole job
+        limit = datetime.timedelta(seconds=240)
         if args.backend == "nccl":
-            init_process_group(dev, rank=rank, world_size=world)
+            init_process_group(dev, rank=rank, world_size=world, timeout=limit)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
     # the collectives of the N > 1 path: RCCL on device tensors, or (rehearsal) gloo through host copies
     coll = dist if args.backend == "nccl" else HostStagedCollectives(dist)
 
