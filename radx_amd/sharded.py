@@ -92,24 +92,25 @@ class HostStagedCollectives:
 class HipEngine:
     """split / local sort through libradx_hip.so on one device."""
 
-    def __init__(self, capacity, key_bytes=4, device=0):
+    def __init__(self, capacity, key_bytes=4, device=0, value_bytes=0):
         from .sorter import Sorter
         self.key_bytes = key_bytes
-        self.sorter = Sorter(capacity, key_bytes, 0, device)
+        self.value_bytes = value_bytes
+        self.sorter = Sorter(capacity, key_bytes, value_bytes, device)
 
-    def msd_split(self, src, dst, n, log2_ranks):
-        """Stable partition of src[:n] into dst[:n] on the top digit, runs in (sub-bucket, rank)
-        order; returns the 16 run starts followed by n."""
+    def msd_split(self, src, dst, n, log2_ranks, vsrc=None, vdst=None):
+        """Stable partition of src[:n] (and the payloads vsrc[:n]) into dst[:n] (vdst[:n]) on the
+        top digit, runs in (sub-bucket, rank) order; returns the 16 run starts followed by n."""
         if n == 0:  # a rank with nothing to contribute: 16 empty runs (the C ABI reports the same)
             return np.zeros(17, dtype=np.uint32)
-        self.sorter.msd_split(src, dst, log2_ranks, n=n)
+        self.sorter.msd_split(src, dst, log2_ranks, vsrc, vdst, n=n)
         return self.sorter.digit_starts()
 
-    def sort_bits(self, keys, swap, n, begin_bit, end_bit):
-        self.sorter.sort_bits(keys, swap, begin_bit, end_bit, n=n)
+    def sort_bits(self, keys, swap, n, begin_bit, end_bit, vals=None, vswap=None):
+        self.sorter.sort_bits(keys, swap, begin_bit, end_bit, vals, vswap, n=n)
 
-    def sort_bits_into(self, keys, swap, out, n, begin_bit, end_bit):
-        self.sorter.sort_bits_into(keys, swap, out, begin_bit, end_bit, n=n)
+    def sort_bits_into(self, keys, swap, out, n, begin_bit, end_bit, vals=None, vswap=None, vout=None):
+        self.sorter.sort_bits_into(keys, swap, out, begin_bit, end_bit, vals, vswap, vout, n=n)
 
     def close(self):
         self.sorter.close()
@@ -122,6 +123,12 @@ class ShardedSorter:
     (capacity >= n_local and >= the shard this rank ends up with plus a few elements of
     alignment padding; `suggest_capacity` gives n_local plus slack for near-uniform keys).
     `stage` is allocated on first use when not given.  The shard is returned as a view of `keys`.
+
+    With uint32 payloads (`vals`, and `vals_work` / `vals_stage` of the same capacity; the engine
+    must have been made with value_bytes=4) every key's payload travels with it: through the
+    split, through a second all-to-all-v with the same splits, through the local passes; the
+    shard's payloads end in vals[:shard_len].  Ties keep the order (source rank, position in that
+    rank's input), i.e. the whole sort is stable over the concatenation of the ranks' inputs.
     """
 
     def __init__(self, engine, group=None, key_bits=32, exchange_when_alone=False, dist=None, profile=False):
@@ -141,6 +148,7 @@ class ShardedSorter:
         # the whole pipeline through the real backend on a single GPU
         self.exchange_when_alone = exchange_when_alone
         self._stage = None
+        self._vals_stage = None
         self._side = None  # stream the local passes run on (device tensors only)
         # profile: bracket the phases of every sort with events (device tensors only); timeline()
         # reports the last sort's
@@ -151,10 +159,10 @@ class ShardedSorter:
     def suggest_capacity(n_local, slack=0.05):
         return int(n_local * (1.0 + slack)) + 4096
 
-    def plan(self, matrix):
+    def plan(self, matrix, align=None):
         """From the gathered [source][16] run lengths: per sub-bucket j the receive counts by source,
         the region length, its exact start in the packed shard and its aligned start in `stage`."""
-        G, S, a = self.world, 16 // self.world, self.align
+        G, S, a = self.world, 16 // self.world, align or self.align
         recv = np.stack([matrix[:, j * G + self.rank] for j in range(S)])  # [j][source]
         length = recv.sum(axis=1)
         exact = np.concatenate([[0], np.cumsum(length)[:-1]])
@@ -163,19 +171,33 @@ class ShardedSorter:
             staged[j] = -(-(staged[j - 1] + length[j - 1]) // a) * a
         return recv, length, exact, staged
 
-    def sort(self, keys, work, n_local, stage=None):
+    def sort(self, keys, work, n_local, stage=None, vals=None, vals_work=None, vals_stage=None):
         """Returns (shard_view_of_keys, shard_len, send_counts[G], recv_counts[G])."""
         import torch
         G, b = self.world, self.log2_world
         if keys.numel() < n_local or work.numel() < n_local:
             raise ValueError("keys/work hold fewer than n_local elements")
+        kv = vals is not None
+        if kv and (vals_work is None or vals.numel() < keys.numel() or vals_work.numel() < work.numel()):
+            raise ValueError("payloads need vals and vals_work of the keys' capacity")
         if G == 1 and not self.exchange_when_alone:
-            self.engine.sort_bits(keys, work, n_local, 0, self.key_bits)
+            if kv:
+                self.engine.sort_bits(keys, work, n_local, 0, self.key_bits, vals, vals_work)
+            else:
+                self.engine.sort_bits(keys, work, n_local, 0, self.key_bits)
             return keys[:n_local], n_local, np.array([n_local]), np.array([n_local])
         if stage is None:
             if self._stage is None or self._stage.numel() < keys.numel() or self._stage.device != keys.device:
                 self._stage = torch.empty_like(keys)
             stage = self._stage
+        if kv and vals_stage is None:
+            if (self._vals_stage is None or self._vals_stage.numel() < vals.numel()
+                    or self._vals_stage.device != vals.device):
+                self._vals_stage = torch.empty_like(vals)
+            vals_stage = self._vals_stage
+        # regions start 16-byte aligned in `stage`; with 4-byte payloads beside 8-byte keys that
+        # means a multiple of 4 elements
+        align = max(self.align, 4) if kv else self.align
         S = 16 // G
 
         marks = None
@@ -185,13 +207,18 @@ class ShardedSorter:
             marks["start"].record()
 
         # 1. stable split on the top digit: keys -> work, runs in (sub-bucket, destination rank) order
-        starts = self.engine.msd_split(keys, work, n_local, b).astype(np.int64)
+        if kv:
+            starts = self.engine.msd_split(keys, work, n_local, b, vals, vals_work).astype(np.int64)
+        else:
+            starts = self.engine.msd_split(keys, work, n_local, b).astype(np.int64)
         if marks:
             marks["split"].record()
         runs = np.diff(starts)  # 16 run lengths; starts[16] == n_local
 
         # 2. every rank learns the whole [source][16] matrix of run lengths, and every rank's capacity
         capacity = min(keys.numel(), stage.numel())
+        if kv:
+            capacity = min(capacity, vals.numel(), vals_stage.numel())
         mine = torch.tensor(np.append(runs, capacity), dtype=torch.int64, device=keys.device)
         gathered = torch.empty(G * 17, dtype=torch.int64, device=keys.device)
         self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
@@ -200,12 +227,12 @@ class ShardedSorter:
         # Every rank checks every rank's shard against that rank's buffers, so that all of them
         # raise together instead of one leaving the others waiting in the exchange.
         shard_lens = matrix.reshape(G, S, G).sum(axis=(0, 1))       # [destination rank]
-        padded = shard_lens + (S - 1) * (self.align - 1)            # worst-case staging padding
+        padded = shard_lens + (S - 1) * (align - 1)                 # worst-case staging padding
         if np.any(padded > capacities):
             r = int(np.argmax(padded - capacities))
             raise RuntimeError("rank %d receives %d keys (up to %d with alignment padding) but its buffers hold %d: "
                                "allocate more slack" % (r, shard_lens[r], padded[r], capacities[r]))
-        recv, length, exact, staged = self.plan(matrix)
+        recv, length, exact, staged = self.plan(matrix, align)
         total = int(length.sum())
 
         # 3. the exchange, one all-to-all-v per sub-bucket, all in flight at once
@@ -213,21 +240,29 @@ class ShardedSorter:
         for j in range(S):
             lo, hi = int(starts[j * G]), int(starts[(j + 1) * G])
             c, m = int(staged[j]), int(length[j])
-            pending.append(self.dist.all_to_all_single(
+            pending.append([self.dist.all_to_all_single(
                 stage[c:c + m], work[lo:hi], output_split_sizes=recv[j].tolist(),
-                input_split_sizes=runs[j * G:(j + 1) * G].tolist(), group=self.group, async_op=True))
+                input_split_sizes=runs[j * G:(j + 1) * G].tolist(), group=self.group, async_op=True)])
+            if kv:
+                pending[j].append(self.dist.all_to_all_single(
+                    vals_stage[c:c + m], vals_work[lo:hi], output_split_sizes=recv[j].tolist(),
+                    input_split_sizes=runs[j * G:(j + 1) * G].tolist(), group=self.group, async_op=True))
 
         # 4. local LSD passes per region as it lands; the last pass packs it into keys[exact[j]:]
         low_bits = self.key_bits - SPLIT_BITS
 
         def local_passes():
             for j in range(S):
-                pending[j].wait()  # a dependency of the current stream on exchange j, not a host wait
+                for w in pending[j]:
+                    w.wait()  # a dependency of the current stream on exchange j, not a host wait
                 if marks:
                     marks["landed"].append(torch.cuda.Event(enable_timing=True))
                     marks["landed"][-1].record()
                 c, m = int(staged[j]), int(length[j])
-                if m:
+                if m and kv:
+                    self.engine.sort_bits_into(stage[c:], keys[c:], keys[int(exact[j]):], m, 0, low_bits,
+                                               vals_stage[c:], vals[c:], vals[int(exact[j]):])
+                elif m:
                     self.engine.sort_bits_into(stage[c:], keys[c:], keys[int(exact[j]):], m, 0, low_bits)
                 if marks:
                     marks["sorted"].append(torch.cuda.Event(enable_timing=True))

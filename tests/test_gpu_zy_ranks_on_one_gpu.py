@@ -70,6 +70,54 @@ def test_ranks_sharing_one_gpu(device, tmp_path, world, dist_name, key_bytes):
     assert np.array_equal(np.concatenate(shards), np.sort(np.concatenate(inputs)))
 
 
+def _kv_worker(rank, world, port, n_local, key_bytes, out_dir):
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda:0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from radx_amd.sharded import HipEngine, HostStagedCollectives, ShardedSorter
+        sdt = np.int32 if key_bytes == 4 else np.int64
+        tdt = torch.int32 if key_bytes == 4 else torch.int64
+        keys = make_keys("few_distinct", n_local, key_bytes, seed=800 + rank)
+        keys[::3] = make_keys("uniform", n_local, key_bytes, seed=900 + rank)[::3]
+        vals = (np.arange(n_local, dtype=np.int64) + rank * n_local).astype(np.int32)
+        cap = n_local * world + 64
+        eng = HipEngine(cap, key_bytes, 0, value_bytes=4)
+        kbuf, work = (torch.zeros(cap, dtype=tdt, device=dev) for _ in range(2))
+        vbuf, vwork = (torch.zeros(cap, dtype=torch.int32, device=dev) for _ in range(2))
+        sharder = ShardedSorter(eng, key_bits=key_bytes * 8, exchange_when_alone=True, dist=HostStagedCollectives(dist))
+        for _ in range(2):
+            kbuf[:n_local] = torch.from_numpy(keys.view(sdt).copy()).to(dev)
+            vbuf[:n_local] = torch.from_numpy(vals).to(dev)
+            shard, total, send, recv = sharder.sort(kbuf, work, n_local, vals=vbuf, vals_work=vwork)
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "shard%d.npy" % rank), shard.cpu().numpy().view(keys.dtype).copy())
+        np.save(os.path.join(out_dir, "vals%d.npy" % rank), vbuf[:total].cpu().numpy().copy())
+        np.save(os.path.join(out_dir, "input%d.npy" % rank), keys)
+        eng.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,key_bytes", [(2, 4), (4, 8)])
+def test_key_value_ranks_sharing_one_gpu(device, tmp_path, world, key_bytes):
+    """Payloads travel with their keys through the split, the exchange and the local passes; the
+    shards concatenate to the stable sort of all ranks' inputs (payload = global input position)."""
+    import torch.multiprocessing as mp
+    n_local = 90000 + 7
+    mp.spawn(_kv_worker, args=(world, _free_port(), n_local, key_bytes, str(tmp_path)), nprocs=world, join=True)
+    keys = np.concatenate([np.load(tmp_path / ("input%d.npy" % r)) for r in range(world)])
+    got_k = np.concatenate([np.load(tmp_path / ("shard%d.npy" % r)) for r in range(world)])
+    got_v = np.concatenate([np.load(tmp_path / ("vals%d.npy" % r)) for r in range(world)])
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(got_k, keys[order])
+    assert np.array_equal(got_v, order.astype(np.int32))
+
+
 def test_bench_launches_its_own_ranks(device):
     """`python bench.py --gpus 2`, started plainly: the launcher starts two rank processes, they run
     the split / exchange / local-pass path and its cross-rank verification, and rank 0's line comes

@@ -27,7 +27,7 @@ class OracleEngine:
     def _u(self, t, n):
         return t[:n].numpy().view(self.udt)
 
-    def msd_split(self, src, dst, n, log2_ranks):
+    def msd_split(self, src, dst, n, log2_ranks, vsrc=None, vdst=None):
         k = self._u(src, n)
         d = (k >> self.udt(self.bits - 4)).astype(np.uint32)
         # bucket (rank r, sub-bucket j), d = r * S + j, goes to position p = j * G + r
@@ -38,23 +38,39 @@ class OracleEngine:
         cfg = oracle.Config(bits=4, grid=1, wave=64, vec=4)
         counts = np.bincount(p, minlength=16).astype(np.uint32).reshape(1, 16)
         parts = oracle.partition(cfg, counts)
-        dst[:n] = torch.from_numpy(k[np.argsort(p, kind="stable")].view(self.sdt).copy())
+        order = np.argsort(p, kind="stable")
+        dst[:n] = torch.from_numpy(k[order].view(self.sdt).copy())
+        if vsrc is not None:
+            vdst[:n] = vsrc[:n][torch.from_numpy(order)]
         return np.concatenate([parts[0], [n]]).astype(np.uint32)
 
-    def _sorted_on(self, k, begin_bit, end_bit):
+    def _order_on(self, k, begin_bit, end_bit):
         field = (k >> self.udt(begin_bit)) & self.udt((1 << (end_bit - begin_bit)) - 1)
-        return k[np.argsort(field, kind="stable")].view(self.sdt).copy()
+        return np.argsort(field, kind="stable")
 
-    def sort_bits(self, keys, swap, n, begin_bit, end_bit):
-        res = self._sorted_on(self._u(keys, n), begin_bit, end_bit)
+    def sort_bits(self, keys, swap, n, begin_bit, end_bit, vals=None, vswap=None):
+        k = self._u(keys, n)
+        order = self._order_on(k, begin_bit, end_bit)
+        res = k[order].view(self.sdt).copy()
         swap[:n] = -1
         keys[:n] = torch.from_numpy(res)
+        if vals is not None:
+            moved = vals[:n][torch.from_numpy(order)].clone()
+            vswap[:n] = -1
+            vals[:n] = moved
 
-    def sort_bits_into(self, keys, swap, out, n, begin_bit, end_bit):
-        res = self._sorted_on(self._u(keys, n), begin_bit, end_bit)
+    def sort_bits_into(self, keys, swap, out, n, begin_bit, end_bit, vals=None, vswap=None, vout=None):
+        k = self._u(keys, n)
+        order = self._order_on(k, begin_bit, end_bit)
+        res = k[order].view(self.sdt).copy()
+        moved = vals[:n][torch.from_numpy(order)].clone() if vals is not None else None
         keys[:n] = -1  # both ping-pong buffers are scratch
         swap[:n] = -1
         out[:n] = torch.from_numpy(res)
+        if vals is not None:
+            vals[:n] = -1
+            vswap[:n] = -1
+            vout[:n] = moved
 
 
 def _free_port():
@@ -163,3 +179,42 @@ def test_plan_regions_do_not_overlap():
                     if j + 1 < S:
                         assert staged[j] + length[j] <= staged[j + 1]
                         assert exact[j] + length[j] == exact[j + 1]
+
+
+def _kv_worker(rank, world, port, n_local, key_bytes, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from radx_amd.sharded import ShardedSorter
+        sdt = np.int32 if key_bytes == 4 else np.int64
+        tdt = torch.int32 if key_bytes == 4 else torch.int64
+        keys = make_keys("few_distinct", n_local, key_bytes, seed=200 + rank)      # many ties
+        keys[::3] = make_keys("uniform", n_local, key_bytes, seed=300 + rank)[::3]
+        vals = (np.arange(n_local, dtype=np.int64) + rank * n_local).astype(np.int32)  # global input position
+        cap = n_local * world + 64
+        kbuf, work = torch.zeros(cap, dtype=tdt), torch.zeros(cap, dtype=tdt)
+        vbuf, vwork = torch.zeros(cap, dtype=torch.int32), torch.zeros(cap, dtype=torch.int32)
+        kbuf[:n_local] = torch.from_numpy(keys.view(sdt).copy())
+        vbuf[:n_local] = torch.from_numpy(vals)
+        sharder = ShardedSorter(OracleEngine(key_bytes), key_bits=key_bytes * 8, exchange_when_alone=True)
+        shard, total, send, recv = sharder.sort(kbuf, work, n_local, vals=vbuf, vals_work=vwork)
+        np.save(os.path.join(out_dir, "shard%d.npy" % rank), shard.numpy().view(keys.dtype).copy())
+        np.save(os.path.join(out_dir, "vals%d.npy" % rank), vbuf[:total].numpy().copy())
+        np.save(os.path.join(out_dir, "input%d.npy" % rank), keys)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,key_bytes", [(2, 4), (4, 8), (1, 4), (8, 4)])
+def test_sharded_key_value_sort_is_globally_stable(tmp_path, world, key_bytes):
+    """Payload = position in the concatenation of the ranks' inputs: after the sharded sort the
+    shards, concatenated, are the stable sort of that concatenation, payloads included."""
+    n_local = 6000 + 13
+    mp.spawn(_kv_worker, args=(world, _free_port(), n_local, key_bytes, str(tmp_path)), nprocs=world, join=True)
+    keys = np.concatenate([np.load(tmp_path / ("input%d.npy" % r)) for r in range(world)])
+    got_k = np.concatenate([np.load(tmp_path / ("shard%d.npy" % r)) for r in range(world)])
+    got_v = np.concatenate([np.load(tmp_path / ("vals%d.npy" % r)) for r in range(world)])
+    order = np.argsort(keys, kind="stable")
+    assert np.array_equal(got_k, keys[order])
+    assert np.array_equal(got_v, order.astype(np.int32))
