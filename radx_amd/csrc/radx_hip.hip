@@ -1029,14 +1029,20 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
             hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, stream, s->group_sums, g.num_groups,
                                a.n, s->digit_starts);
     }
+    // Workgroups per CU are part of the tuning: every resident tile is 16 more write streams for
+    // the memory system.  4-byte keys alone are fastest at the 5 the registers allow, and so are
+    // 8-byte keys alone; with a payload 4 beat 5 (2^30 uint64 + payload: 77.9 -> 76.5 ms), which
+    // the 4-byte-key variant reaches through its registers and the 8-byte-key variant through
+    // LDS that is requested at launch and never touched.
+    constexpr size_t hold_back = (HAS_V && sizeof(K) == 8) ? 6144 : 0;
     {
         LaunchTimer t(s, 2, stream);
         if (a.fuse_next)
-            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true>), dim3(g.num_tiles), dim3(kBlock), 0, stream,
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true>), dim3(g.num_tiles), dim3(kBlock), hold_back, stream,
                                kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
                                a.next_bit, next_mask, next_counts, a.order_in, a.order_out);
         else
-            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false>), dim3(g.num_tiles), dim3(kBlock), 0, stream,
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false>), dim3(g.num_tiles), dim3(kBlock), hold_back, stream,
                                kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
                                0, 0u, static_cast<uint32_t*>(nullptr), a.order_in, a.order_out);
     }
