@@ -118,8 +118,9 @@ def test_key_value_ranks_sharing_one_gpu(device, tmp_path, world, key_bytes):
     assert np.array_equal(got_v, order.astype(np.int32))
 
 
-def test_bench_launches_its_own_ranks(device):
-    """`python bench.py --gpus 2`, started plainly: the launcher starts two rank processes, they run
+@pytest.mark.parametrize("gpus", [2, 8])
+def test_bench_launches_its_own_ranks(device, gpus):
+    """`python bench.py --gpus N`, started plainly: the launcher starts the rank processes, they run
     the split / exchange / local-pass path and its cross-rank verification, and rank 0's line comes
     back through the launcher.  The ranks share this box's one GPU, hence gloo instead of RCCL."""
     import json
@@ -127,13 +128,13 @@ def test_bench_launches_its_own_ranks(device):
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu",
-                          "--log2n", "21", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras"],
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", str(gpus), "--backend", "gloo", "--share-gpu",
+                          "--log2n", "20", "--steps", "2", "--warmup", "1", "--no-cpu", "--no-extras"],
                          capture_output=True, text=True, timeout=400, env=env, cwd=root)
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["verified"] is True and line["scaling"] == "weak"
-    assert line["config"]["total_keys"] == 2 << 21 and line["exchange"]["all_to_all_calls_per_step"] == 8
+    assert line["n_gpus"] == gpus and line["verified"] is True and line["scaling"] == "weak"
+    assert line["config"]["total_keys"] == gpus << 20 and line["exchange"]["all_to_all_calls_per_step"] == 16 // gpus
     assert line["roofline"]["launches"] > 0
