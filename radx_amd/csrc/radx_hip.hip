@@ -964,6 +964,7 @@ hipError_t harvest_timings(radx_hip_sorter* s, bool wait) {
         s->pool.push_back(t);
     }
     s->pending.resize(kept);
+    if (!wait) (void)hipGetLastError();  // a "not ready" answer must not surface as the next launch's error
     return first_error;
 }
 constexpr size_t kMaxPendingTimings = 1024;  // ~40 sorts' worth; beyond it finished ones are folded in

@@ -471,3 +471,25 @@ def test_sort_is_graph_capturable(device):
         torch.cuda.synchronize()
         assert np.array_equal(to_host(k), np.sort(keys)), seed
     s.close()
+
+
+def test_profiling_for_a_long_time_without_reading(device):
+    """More launches than the pending-timings list holds (1024) before kernel_times is read: the
+    finished ones are folded in along the way, nothing is lost and no sort fails."""
+    import torch
+    import radx_amd
+    n = 300 * 4096 + 1  # 2 scan groups: 25 launches per sort
+    keys = make_keys("uniform", n, 4, seed=3)
+    s = radx_amd.Sorter(n, 4, 0)
+    s.profile(True)
+    k = to_dev(keys, device)
+    swap = torch.empty_like(k)
+    sorts = 90
+    for _ in range(sorts):
+        s.sort(k, swap)
+    torch.cuda.synchronize()
+    t = s.kernel_times()
+    assert t["scatter"][1] == 8 * sorts and t["hist"][1] == sorts and t["scan"][1] == 8 * sorts
+    assert t["scatter"][0] > 0
+    assert np.array_equal(to_host(k), np.sort(keys))
+    s.close()
