@@ -218,3 +218,36 @@ def test_sharded_key_value_sort_is_globally_stable(tmp_path, world, key_bytes):
     order = np.argsort(keys, kind="stable")
     assert np.array_equal(got_k, keys[order])
     assert np.array_equal(got_v, order.astype(np.int32))
+
+
+def _staged_worker(rank, world, port, n_local, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from radx_amd.sharded import HostStagedCollectives, ShardedSorter
+        coll = HostStagedCollectives(dist)
+        assert coll.get_world_size() == world and coll.get_rank() == rank
+        keys = make_keys("hash", n_local, 4, seed=600 + rank)
+        cap = ShardedSorter.suggest_capacity(n_local, 0.3)
+        kbuf, work = torch.zeros(cap, dtype=torch.int32), torch.zeros(cap, dtype=torch.int32)
+        kbuf[:n_local] = torch.from_numpy(keys.view(np.int32).copy())
+        shard, total, send, recv = ShardedSorter(OracleEngine(4), dist=coll).sort(kbuf, work, n_local)
+        t = torch.tensor([total], dtype=torch.int64)
+        coll.all_reduce(t)
+        assert int(t.item()) == n_local * world
+        coll.barrier()
+        np.save(os.path.join(out_dir, "shard%d.npy" % rank), shard.numpy().view(np.uint32).copy())
+        np.save(os.path.join(out_dir, "input%d.npy" % rank), keys)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_host_staged_collectives_adapter(tmp_path):
+    """The adapter that carries the collectives through host copies (used to rehearse the
+    multi-rank path where ranks share a GPU) behaves like torch.distributed for the sorter."""
+    world = 4
+    mp.spawn(_staged_worker, args=(world, _free_port(), 9000 + 5, str(tmp_path)), nprocs=world, join=True)
+    shards = [np.load(tmp_path / ("shard%d.npy" % r)) for r in range(world)]
+    inputs = [np.load(tmp_path / ("input%d.npy" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate(shards), np.sort(np.concatenate(inputs)))
