@@ -22,7 +22,8 @@ if vb:
     vswap = torch.empty_like(v)
 s = radx_amd.Sorter(n, kb, vb)
 s.tune(bool(fuse))
-s.profile(True)
+import os
+s.profile(os.environ.get('QB_PROFILE', '1') == '1')  # QB_PROFILE=0: no per-launch events (for kernel traces)
 passes = kb * 2
 totals, scatters = [], []
 for it in range(iters):
