@@ -49,6 +49,24 @@ constexpr int kThreadDwords = 16;       // every thread owns 64 B of keys
 constexpr int kTileDwords = kBlock * kThreadDwords;  // 16 KiB of keys per tile
 constexpr int kCtrRows = kRadices / 2;  // packed counters: digit d lives in row d&7, half d>>3
 constexpr int kScanBlocks = 256;        // table rows (workgroups) scanned by one scan workgroup
+// Inputs of at most kScanlessMaxTiles tiles run without scan kernels: a few extra workgroups of
+// the scatter launch publish the column sums of every group of kGroupTiles table rows, and every
+// scatter workgroup derives its own 16 output bases from those sums and the rows of its own group.
+constexpr int kLogGroupTiles = 6;
+constexpr uint32_t kGroupTiles = 1u << kLogGroupTiles;
+constexpr uint32_t kScanlessMaxTiles = 8192;
+constexpr int kGroupIters = kScanlessMaxTiles / kGroupTiles / 16;  // group rows per 16-lane team: 8
+constexpr int kRowIters = kGroupTiles / 16;                       // own-group rows per 16-lane team: 4
+constexpr uint32_t kGroupValid = 0x80000000u;  // a published group sum (below 2^25: 8192 tiles of 4096 keys) carries this bit
+constexpr int kMaxPolls = 64;                  // looks at an unpublished word before a workgroup sums the table itself
+// One buffer of group words: kMaxGroups rows of 16 column sums, then kMaxGroups rows of 16 output bases.
+constexpr uint32_t kMaxGroups = kScanlessMaxTiles / kGroupTiles;
+constexpr uint32_t kGroupBaseWords = kMaxGroups * 16;  // where the bases start
+// Up to this many groups every tile workgroup adds up the group sums itself (2 table rows per
+// team of 16 lanes) instead of waiting for the scanning workgroup's bases: one step less in the
+// chain, which counts when the whole launch is one round of workgroups.
+constexpr uint32_t kOneLevelGroups = 32;
+constexpr int kOneLevelIters = kOneLevelGroups / 16;
 
 template <typename K> struct KeyTraits;
 template <> struct KeyTraits<uint32_t> { static constexpr int kpt = 16; static constexpr int log_tile = 12; };
@@ -207,7 +225,10 @@ __device__ __forceinline__ uint32_t tile_image_dword(uint32_t row, uint32_t c) {
 template <typename K>
 __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys, uint32_t n, int bit,
                                                        uint32_t mask, uint32_t* __restrict__ counts,
-                                                       uint32_t num_tiles, int order_in) {
+                                                       uint32_t num_tiles, int order_in,
+                                                       uint32_t* __restrict__ zero_counts,
+                                                       uint32_t* __restrict__ zero_groups_a,
+                                                       uint32_t* __restrict__ zero_groups_b) {
     constexpr int KPT = KeyTraits<K>::kpt;
     constexpr uint32_t TILE = kBlock * KPT;
     constexpr int PER_VEC = 16 / sizeof(K);
@@ -264,6 +285,15 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
         const uint32_t d = tid >> 5;
         counts[static_cast<size_t>(g) * kRadices + d] = lo;
         counts[static_cast<size_t>(g) * kRadices + d + 8u] = hi;
+    }
+    // scan-free mode: the table the first scatter adds into, and the group sums of the first two passes
+    if (zero_counts && tid < static_cast<uint32_t>(kRadices)) zero_counts[static_cast<size_t>(g) * kRadices + tid] = 0u;
+    if (zero_groups_a) {
+        const uint32_t w = blockIdx.x * kBlock + tid;
+        if (w < ((num_tiles + kGroupTiles - 1u) >> kLogGroupTiles) * kRadices) {
+            zero_groups_a[w] = 0u; zero_groups_a[kGroupBaseWords + w] = 0u;
+            zero_groups_b[w] = 0u; zero_groups_b[kGroupBaseWords + w] = 0u;
+        }
     }
 }
 
@@ -416,13 +446,44 @@ __global__ __launch_bounds__(1024) void scan_groups_kernel(uint32_t* __restrict_
 //      tile (a run crosses at most one tile boundary) are rare and use a plain 16x16 table.
 //      After the last store the sums are added to next_counts[destination tile][next digit].
 // ---------------------------------------------------------------------------------------------
-template <typename K, bool HAS_V, bool FUSE>
-__global__ __launch_bounds__(kBlock) void scatter_kernel(
+// What only the scan-free mode touches.
+struct ScanFreeTables {
+    uint32_t* group_words;     // this pass's group sums and bases: cleared before the launch, published by its first workgroups
+    uint32_t* zero_counts;     // the table the pass after the next accumulates into: cleared row by row here
+    uint32_t* zero_group_words;  // and the group words of the pass after the next
+    uint32_t* digit_starts;    // the 17 run starts
+    int publish;               // tests only: 0 nothing is published, 2 only the bases are (1: everything)
+};
+
+// SCANLESS: no scan kernel runs for this pass; the scan is done by a few extra workgroups at the
+// front of the launch (their number rounded up to 8, which keeps the XCD of every tile workgroup).
+//   * Extra workgroup b < ceil(num_tiles / 64) sums the 16 columns of table rows [64 b, 64 b + 64)
+//     of `counts` and publishes the 16 sums.
+//   * The next extra workgroup waits for those sums, scans them in (digit, group) order and
+//     publishes, per group, the 16 output bases of the group's first tile (and the 17 run starts).
+//   * The workgroup of tile g reads the 16 bases of its group and the table rows of its own group
+//     in front of g (at most 63, one dword per lane and row, 16 lanes to a row), and stores its 16
+//     bases to offsets[g] (the reference's partitions[g][r], partition.comp:26) for readers of the
+//     tables.
+// A published word carries bit 31 (the values stay below 2^26) and is written with one agent-scope
+// store and read with agent-scope loads: value and "is there" travel in one word, so no fences.
+// Tile workgroups look for their bases only after their keys are loaded and counted in LDS; the
+// publishing workgroups have the lowest numbers, so they run first.  Nobody waits without a
+// bound: whoever still misses a word after kMaxPolls looks sums the table itself — the scanning
+// workgroup its group sums, a tile workgroup its 16 bases — so no workgroup's completion depends
+// on another one's progress.  Tables rotate through three buffers: this pass's are read, the
+// next pass's are added to, the ones after that are cleared.
+// Keys alone run fastest with 5 workgroups per CU, which 4-byte keys reach at 96 registers: the
+// scan-free variant would take 98 without the bound (no spills with it).
+template <typename K, bool HAS_V> constexpr int scatter_min_waves() { return sizeof(K) == 4 && !HAS_V ? 5 : 1; }
+
+template <typename K, bool HAS_V, bool FUSE, bool SCANLESS>
+__global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatter_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* __restrict__ vin,
     uint32_t* __restrict__ vout, uint32_t n, int bit, uint32_t mask,
-    const uint32_t* __restrict__ counts, const uint32_t* __restrict__ offsets, const uint32_t* __restrict__ group_sums,
+    const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets, const uint32_t* __restrict__ group_sums,
     uint32_t num_tiles, int next_bit, uint32_t next_mask, uint32_t* __restrict__ next_counts,
-    int order_in, int order_out) {
+    int order_in, int order_out, ScanFreeTables sf) {
     constexpr int KPT = KeyTraits<K>::kpt;
     constexpr int LOG_TILE = KeyTraits<K>::log_tile;
     constexpr uint32_t TILE = kBlock * KPT;
@@ -453,19 +514,168 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     __shared__ __attribute__((aligned(16))) uint4 where_s[kRadices];
     __shared__ uint32_t padpack_s[ALIGNED ? kCtrRows : 1];  // empty slots in front of digits r (low half) and r + 8 (high half)
     __shared__ uint32_t wave_tot[kBlock / 64];
+    __shared__ uint32_t part_s[SCANLESS ? (kBlock / 64) * 2 * kRadices : 1];  // per wave: 16 digit totals, 16 sums in front of the tile
+    __shared__ uint32_t self_sum_s;  // SCANLESS: some group sum never showed up, sum the table here
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const uint32_t g = tile_of_workgroup<xcd_block<K, HAS_V>()>(blockIdx.x, num_tiles);
+    // SCANLESS: team = tid / 16 of 16 lanes reads table rows team, team + 16, ...; lane col of a team reads column col
+    const uint32_t tcol = tid & 15u, team = tid >> 4;
+    const uint32_t num_grps = (num_tiles + kGroupTiles - 1u) >> kLogGroupTiles;
+    const uint32_t publishers = SCANLESS ? (num_grps + 1u + 7u) & ~7u : 0u;
+    if (SCANLESS && blockIdx.x < publishers) {
+        const uint32_t b = blockIdx.x;
+        if (b > num_grps || sf.publish == 0) return;
+        if (b == num_grps && num_grps <= kOneLevelGroups) return;  // nobody reads the bases
+        if (b < num_grps) {  // the column sums of one group of table rows
+            if (sf.publish != 1) return;
+            uint32_t sum = 0;
+#pragma unroll
+            for (int i = 0; i < kRowIters; ++i) {
+                const uint32_t r = b * kGroupTiles + team + 16u * i;
+                if (r < num_tiles) sum += counts[static_cast<size_t>(r) * kRadices + tcol];
+            }
+            sum += __shfl_xor(sum, 16, 64);
+            sum += __shfl_xor(sum, 32, 64);
+            if (lane < static_cast<uint32_t>(kRadices)) part_s[wave * kRadices + lane] = sum;
+            __syncthreads();
+            if (tid < static_cast<uint32_t>(kRadices)) {
+                sum = 0;
+#pragma unroll
+                for (int w = 0; w < kBlock / 64; ++w) sum += part_s[w * kRadices + tid];
+                __hip_atomic_store(&sf.group_words[b * kRadices + tid], sum | kGroupValid, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+            }
+            return;
+        }
+        // The scan over the groups.  Team t owns groups 8t .. 8t+7, lane c of a team column c.
+        uint32_t w[kGroupIters];
+        bool have = false;
+        for (int looks = 1; looks <= kMaxPolls; ++looks) {
+            uint32_t there = kGroupValid;
+#pragma unroll
+            for (int i = 0; i < kGroupIters; ++i) {
+                const uint32_t r = team * kGroupIters + i;
+                w[i] = r < num_grps ? __hip_atomic_load(&sf.group_words[r * kRadices + tcol], __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT)
+                                    : kGroupValid;
+                there &= w[i];
+            }
+            have = __syncthreads_and(static_cast<int>(there >> 31)) != 0;
+            if (have) break;
+            __builtin_amdgcn_s_sleep(16);
+        }
+        if (!have) {  // never in practice: the group sums straight from the table
+#pragma unroll 1
+            for (int i = 0; i < kGroupIters; ++i) {
+                const uint32_t r = team * kGroupIters + i;
+                uint32_t sum = 0;
+                for (uint32_t t = r * kGroupTiles; t < min((r + 1u) * kGroupTiles, num_tiles); ++t)
+                    sum += counts[static_cast<size_t>(t) * kRadices + tcol];
+                w[i] = sum;
+            }
+        }
+        uint32_t mine = 0;  // this team's groups, this column
+#pragma unroll
+        for (int i = 0; i < kGroupIters; ++i) { w[i] &= ~kGroupValid; mine += w[i]; }
+        uint32_t incl = mine;  // over the teams of this wave
+        uint32_t up = __shfl_up(incl, 16, 64);
+        if (lane >= 16u) incl += up;
+        up = __shfl_up(incl, 32, 64);
+        if (lane >= 32u) incl += up;
+        if (lane >= 48u) part_s[wave * kRadices + tcol] = incl;
+        __syncthreads();
+        uint32_t before = incl - mine, all = 0;
+#pragma unroll
+        for (int v = 0; v < kBlock / 64; ++v) {
+            const uint32_t t = part_s[v * kRadices + tcol];
+            if (static_cast<uint32_t>(v) < wave) before += t;
+            all += t;
+        }
+        if (wave == 0u) {  // every digit's run start: exclusive scan of the 16 digit totals (lanes 0..15)
+            const uint32_t tot = lane < static_cast<uint32_t>(kRadices) ? all : 0u;
+            const uint32_t start = wave_inclusive_scan(tot) - tot;
+            if (lane < static_cast<uint32_t>(kRadices)) {
+                part_s[(kBlock / 64) * kRadices + lane] = start;
+                sf.digit_starts[lane] = start;
+            }
+            if (lane == 0u) sf.digit_starts[kRadices] = n;
+        }
+        __syncthreads();
+        uint32_t run = part_s[(kBlock / 64) * kRadices + tcol] + before;
+#pragma unroll
+        for (int i = 0; i < kGroupIters; ++i) {
+            const uint32_t r = team * kGroupIters + i;
+            if (r < num_grps)
+                __hip_atomic_store(&sf.group_words[kGroupBaseWords + r * kRadices + tcol], run | kGroupValid,
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            run += w[i];
+        }
+        return;
+    }
+    const uint32_t g = tile_of_workgroup<xcd_block<K, HAS_V>()>(blockIdx.x - publishers, num_tiles);
     const uint32_t base = g * TILE;
     const uint32_t valid = min(TILE, n - base);
 
     // Global output base of every digit for this tile; issued first, consumed after the scan.
     uint32_t run_base = 0, run_len = 0;
-    if (tid < static_cast<uint32_t>(kRadices)) {
+    const uint32_t my_grp = g >> kLogGroupTiles, in_grp = g & (kGroupTiles - 1u);
+    uint32_t base_word = kGroupValid, grp_word[SCANLESS ? kOneLevelIters : 1], row_word[SCANLESS ? kRowIters : 1];
+    const bool one_level = num_grps <= kOneLevelGroups;
+    // One level: every team's group sums (rows past the end re-read the last one and are masked
+    // when summed).  Two levels: lanes 0..15 of wave 0 read the output bases of this tile's group.
+    auto look_at_group_words = [&]() {
+        if (one_level) {
+#pragma unroll
+            for (int i = 0; i < kOneLevelIters; ++i) {
+                grp_word[i] = kGroupValid;
+                if (16u * i < num_grps)  // uniform
+                    grp_word[i] = __hip_atomic_load(&sf.group_words[min(team + 16u * i, num_grps - 1u) * kRadices + tcol],
+                                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        } else if (tid < static_cast<uint32_t>(kRadices)) {
+            base_word = __hip_atomic_load(&sf.group_words[kGroupBaseWords + my_grp * kRadices + tid], __ATOMIC_RELAXED,
+                                          __HIP_MEMORY_SCOPE_AGENT);
+        }
+    };
+    // The first round of workgroups starts together with the publishers: they look after loading
+    // and counting their keys.  Later workgroups find the words published and look right away.
+    const bool late_look = blockIdx.x - publishers < 1024u;
+    if (SCANLESS) {
+        if (tid == 0u) self_sum_s = 0u;
+        if (!late_look) look_at_group_words();
+#pragma unroll
+        for (int i = 0; i < kRowIters; ++i) {
+            row_word[i] = 0u;
+            if (16u * i < in_grp)
+                row_word[i] = counts[static_cast<size_t>(my_grp * kGroupTiles + min(team + 16u * i, in_grp - 1u)) * kRadices + tcol];
+        }
+        if (ALIGNED && tid < static_cast<uint32_t>(kRadices)) run_len = counts[static_cast<size_t>(g) * kRadices + tid];
+    } else if (tid < static_cast<uint32_t>(kRadices)) {
         run_base = offsets[static_cast<size_t>(g) * kRadices + tid] +
                    group_sums[static_cast<size_t>(tid) * ((num_tiles + kScanBlocks - 1) / kScanBlocks) + g / kScanBlocks];
         if (ALIGNED) run_len = counts[static_cast<size_t>(g) * kRadices + tid];
     }
+    // wave 0, ALIGNED only: the slot layout of the padded rank-ordered array, from the tile's own
+    // histogram row and the output bases (lanes 0..15 hold digit d's key count and global base)
+    auto place_runs = [&]() {
+        // The digit's first slot is its tile rank start plus a pad that makes slot = output index
+        // (mod ALIGN_E); pads must not decrease from digit to digit, hence the 16-step recurrence.
+        const uint32_t start = wave_inclusive_scan(run_len) - run_len;
+        const uint32_t want = (run_base - start) & (ALIGN_E - 1u);
+        uint32_t pad = 0, prev = 0;
+#pragma unroll
+        for (int d = 0; d < kRadices; ++d) {
+            const uint32_t mine = prev + ((want - prev) & (ALIGN_E - 1u));
+            if (lane == static_cast<uint32_t>(d)) pad = mine;
+            prev = __builtin_amdgcn_readlane(mine, d);
+        }
+        const uint32_t hi = __shfl_down(pad, 8, 64);
+        if (tid < static_cast<uint32_t>(kRadices)) {
+            const uint32_t first = start + pad;
+            where_s[tid] = make_uint4(run_base - first, run_base | (TILE - 1u), first, run_len);
+            if (tid < static_cast<uint32_t>(kCtrRows)) padpack_s[tid] = pad | (hi << 16);
+        }
+    };
 
     K key[KPT];
     uint32_t val[HAS_V ? KPT : 1];
@@ -516,25 +726,11 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
             for (int i = 0; i < KPT; ++i) val[i] = vin[base + min(tid * KPT + i, valid - 1u)];
         }
     }
-    if (ALIGNED && wave == 0u) {
-        // Lanes 0..15 hold digit d's key count and global output base.  The digit's first slot
-        // is its tile rank start plus a pad that makes slot = output index (mod ALIGN_E); pads
-        // must not decrease from digit to digit, hence the 16-step recurrence.
-        const uint32_t start = wave_inclusive_scan(run_len) - run_len;
-        const uint32_t want = (run_base - start) & (ALIGN_E - 1u);
-        uint32_t pad = 0, prev = 0;
+    if (!SCANLESS && ALIGNED && wave == 0u) place_runs();
+    uint32_t bef_rows = 0;  // SCANLESS: this team's share of the own group's rows in front of the tile
+    if (SCANLESS) {
 #pragma unroll
-        for (int d = 0; d < kRadices; ++d) {
-            const uint32_t mine = prev + ((want - prev) & (ALIGN_E - 1u));
-            if (lane == static_cast<uint32_t>(d)) pad = mine;
-            prev = __builtin_amdgcn_readlane(mine, d);
-        }
-        const uint32_t hi = __shfl_down(pad, 8, 64);
-        if (tid < static_cast<uint32_t>(kRadices)) {
-            const uint32_t first = start + pad;
-            where_s[tid] = make_uint4(run_base - first, run_base | (TILE - 1u), first, run_len);
-            if (tid < static_cast<uint32_t>(kCtrRows)) padpack_s[tid] = pad | (hi << 16);
-        }
+        for (int i = 0; i < kRowIters; ++i) bef_rows += team + 16u * i < in_grp ? row_word[i] : 0u;
     }
     __syncthreads();
 #pragma unroll
@@ -550,6 +746,7 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
     // 2. thread-private packed counters.
 #pragma unroll
     for (int r = 0; r < kCtrRows; ++r) ctr[r * kBlock + tid] = 0u;
+    if (SCANLESS && late_look) look_at_group_words();  // in flight during the counting below
     // Ranks (below the tile size) stay in registers until the keys — and, with a payload, the
     // values much later — go to LDS.  With a payload they are packed two to a register to ease
     // the pressure over that long range (uint64 + payload: 83.0 -> 81.1 ms per 2^30 sort);
@@ -567,7 +764,79 @@ __global__ __launch_bounds__(kBlock) void scatter_kernel(
         if (PACK) rank[i / 2] = (i & 1) ? rank[i / 2] | (r << 16) : r;
         else rank[i] = r;
     }
+    if (SCANLESS) {
+        if (one_level || wave == 0u) {
+            for (int looks = 1;; ++looks) {
+                uint32_t there = base_word;
+#pragma unroll
+                for (int i = 0; i < kOneLevelIters; ++i) there &= one_level ? grp_word[i] : kGroupValid;
+                if (__all(static_cast<int>(there >> 31))) break;
+                if (looks == kMaxPolls) { if (lane == 0u) self_sum_s = 1u; break; }  // every writer writes 1
+                __builtin_amdgcn_s_sleep(8);
+                look_at_group_words();
+            }
+        }
+        // The rows of the tile's own group in front of it (and, one level, the group sums): every
+        // team's partial column sums, then the 4 teams of a wave.
+        uint32_t tot = 0, bef = bef_rows;
+        if (one_level) {
+#pragma unroll
+            for (int i = 0; i < kOneLevelIters; ++i) {
+                const uint32_t r = team + 16u * i, w = grp_word[i] & ~kGroupValid;
+                tot += r < num_grps ? w : 0u;
+                bef += r < my_grp ? w : 0u;
+            }
+        }
+        tot += __shfl_xor(tot, 16, 64); bef += __shfl_xor(bef, 16, 64);
+        tot += __shfl_xor(tot, 32, 64); bef += __shfl_xor(bef, 32, 64);
+        if (lane < static_cast<uint32_t>(kRadices)) {
+            part_s[wave * 2 * kRadices + lane] = tot;
+            part_s[wave * 2 * kRadices + kRadices + lane] = bef;
+        }
+    }
     __syncthreads();
+    if (SCANLESS) {
+        if (self_sum_s) {  // uniform.  Never taken in practice: the column sums straight from the table.
+            uint32_t tot = 0, bef = 0;
+            for (uint32_t r = team; r < num_tiles; r += 16u) {
+                const uint32_t w = counts[static_cast<size_t>(r) * kRadices + tcol];
+                tot += w;
+                bef += r < g ? w : 0u;
+            }
+            tot += __shfl_xor(tot, 16, 64); bef += __shfl_xor(bef, 16, 64);
+            tot += __shfl_xor(tot, 32, 64); bef += __shfl_xor(bef, 32, 64);
+            if (lane < static_cast<uint32_t>(kRadices)) {
+                part_s[wave * 2 * kRadices + lane] = tot;
+                part_s[wave * 2 * kRadices + kRadices + lane] = bef;
+            }
+            __syncthreads();
+        }
+        if (wave == 0u) {
+            uint32_t tot = 0, bef = 0;
+            if (lane < static_cast<uint32_t>(kRadices)) {
+#pragma unroll
+                for (int w = 0; w < kBlock / 64; ++w) {
+                    tot += part_s[w * 2 * kRadices + lane];
+                    bef += part_s[w * 2 * kRadices + kRadices + lane];
+                }
+            }
+            // the group's bases, or (having summed the table here) the digit starts: lanes past 15 add 0
+            const uint32_t scanned = wave_inclusive_scan(tot) - tot;
+            const uint32_t start = (one_level || self_sum_s) ? scanned : base_word & ~kGroupValid;
+            run_base = start + bef;
+            if (lane < static_cast<uint32_t>(kRadices)) {
+                offsets[static_cast<size_t>(g) * kRadices + lane] = run_base;
+                sf.zero_counts[static_cast<size_t>(g) * kRadices + lane] = 0u;
+                if (g < num_grps) {
+                    sf.zero_group_words[g * kRadices + lane] = 0u;
+                    sf.zero_group_words[kGroupBaseWords + g * kRadices + lane] = 0u;
+                }
+                if (g == 0u && (one_level || sf.publish == 0)) sf.digit_starts[lane] = run_base;  // nobody scanned
+            }
+            if (g == 0u && lane == 0u && (one_level || sf.publish == 0)) sf.digit_starts[kRadices] = n;
+            if (ALIGNED) place_runs();  // read after the next barrier
+        }
+    }
 
     // 3. block-wide exclusive scan, thread t owning words 8t..8t+7 of the row-major counter array.
     {
@@ -875,19 +1144,29 @@ constexpr Geometry geometry_for(uint64_t n, int key_bytes) {
 }
 constexpr size_t align256(size_t b) { return (b + 255u) & ~static_cast<size_t>(255u); }
 
+// counts[0..1] alternate between "scanned this pass" and "accumulated for the next pass".  The
+// scan-free mode (at most kScanlessMaxTiles tiles) rotates through three tables, so counts[2]
+// only has that many rows, and keeps one small table of group sums beside each.
 struct ScratchLayout {
-    size_t counts[2], offsets, group_sums, digit_starts, total;
+    size_t counts[3], group_tot[3], offsets, group_sums, digit_starts, total;
 };
+constexpr size_t kGroupTotBytes = align256(2 * kGroupBaseWords * 4);  // group sums, then group bases
 constexpr ScratchLayout layout_for(uint64_t max_n, int key_bytes) {
     const Geometry g = geometry_for(max_n, key_bytes);
     const size_t table = align256(static_cast<size_t>(g.num_tiles) * kRadices * 4);
+    const uint32_t small_tiles = g.num_tiles < kScanlessMaxTiles ? g.num_tiles : kScanlessMaxTiles;
     ScratchLayout l{};
-    l.counts[0] = 0;
-    l.counts[1] = table;
-    l.offsets = 2 * table;
-    l.group_sums = 3 * table;
-    l.digit_starts = l.group_sums + align256(static_cast<size_t>(g.num_groups) * kRadices * 4);
-    l.total = l.digit_starts + align256(32 * 4);
+    size_t at = 0;
+    l.counts[0] = at;    at += table;
+    l.group_tot[0] = at; at += kGroupTotBytes;
+    l.group_tot[1] = at; at += kGroupTotBytes;
+    l.counts[1] = at;    at += table;
+    l.group_tot[2] = at; at += kGroupTotBytes;
+    l.counts[2] = at;    at += align256(static_cast<size_t>(small_tiles) * kRadices * 4);
+    l.offsets = at;      at += table;
+    l.group_sums = at;   at += align256(static_cast<size_t>(g.num_groups) * kRadices * 4);
+    l.digit_starts = at; at += align256(32 * 4);
+    l.total = at;
     return l;
 }
 
@@ -918,10 +1197,14 @@ struct radx_hip_sorter {
     int key_bytes = 4;
     int value_bytes = 0;
     bool fuse = true;
+    bool scan_kernels = false;  // run the scan kernels even where the scan-free mode applies
+    int publish = 1;            // tests: 0 scan-free workgroups get no bases and sum the table themselves, 2 no group sums
     int key_order = 0;      // kOrderSigned | kOrderFloat | kOrderDescending
     char* scratch = nullptr;
     ScratchLayout layout{};
-    uint32_t* counts[2] = {nullptr, nullptr};
+    uint32_t* counts[3] = {nullptr, nullptr, nullptr};
+    uint32_t* group_tot[3] = {nullptr, nullptr, nullptr};
+    bool tables_scanfree = false;  // the last pass ran scan-free: offsets holds full output bases
     uint32_t* offsets = nullptr;
     uint32_t* group_sums = nullptr;
     uint32_t* digit_starts = nullptr;
@@ -942,8 +1225,10 @@ namespace {
 // Points the sorter's table pointers into `base`, laid out by layout_for.
 void bind_scratch(radx_hip_sorter* s, char* base) {
     s->scratch = base;
-    s->counts[0] = reinterpret_cast<uint32_t*>(base + s->layout.counts[0]);
-    s->counts[1] = reinterpret_cast<uint32_t*>(base + s->layout.counts[1]);
+    for (int i = 0; i < 3; ++i) {
+        s->counts[i] = reinterpret_cast<uint32_t*>(base + s->layout.counts[i]);
+        s->group_tot[i] = reinterpret_cast<uint32_t*>(base + s->layout.group_tot[i]);
+    }
     s->offsets = reinterpret_cast<uint32_t*>(base + s->layout.offsets);
     s->group_sums = reinterpret_cast<uint32_t*>(base + s->layout.group_sums);
     s->digit_starts = reinterpret_cast<uint32_t*>(base + s->layout.digit_starts);
@@ -1013,41 +1298,67 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
     const uint32_t* vin = static_cast<const uint32_t*>(a.vin);
     uint32_t* vout = static_cast<uint32_t*>(a.vout);
 
+    // Small inputs run scan-free (see scatter_kernel): a pass is one launch, the tables rotate
+    // through three buffers.  Otherwise: scan kernels, two buffers.
+    const bool scanfree = s->fuse && !s->scan_kernels && g.num_tiles <= kScanlessMaxTiles;
     if (a.have_counts) {
-        s->cur ^= 1;  // the table the previous scatter filled becomes this pass's histogram
+        // the table the previous scatter filled becomes this pass's histogram
+        s->cur = scanfree ? (s->cur + 1) % 3 : s->cur ^ 1;
     } else {
+        s->cur = 0;
         LaunchTimer t(s, 0, stream);
+        uint32_t* const none = nullptr;
+        // scan-free: it also clears the table the first scatter adds into and the group sums of the first two passes
         hipLaunchKernelGGL(hist_kernel<K>, dim3(g.num_tiles), dim3(kBlock), 0, stream, kin, a.n, a.bit,
-                           mask, s->counts[s->cur], g.num_tiles, a.order_in);
+                           mask, s->counts[0], g.num_tiles, a.order_in, scanfree ? s->counts[1] : none,
+                           scanfree ? s->group_tot[0] : none, scanfree ? s->group_tot[1] : none);
     }
     uint32_t* counts = s->counts[s->cur];
-    uint32_t* next_counts = s->counts[s->cur ^ 1];
-    {
-        LaunchTimer t(s, 1, stream);
-        hipLaunchKernelGGL(scan_rows_kernel, dim3(g.num_groups), dim3(kBlock), 0, stream, counts, s->offsets,
-                           s->group_sums, g.num_tiles, a.fuse_next ? next_counts : static_cast<uint32_t*>(nullptr),
-                           a.n, s->digit_starts);
-        if (g.num_groups > 1)
-            hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, stream, s->group_sums, g.num_groups,
-                               a.n, s->digit_starts);
-    }
+    const int next = scanfree ? (s->cur + 1) % 3 : s->cur ^ 1;
+    uint32_t* next_counts = s->counts[next];
     // Workgroups per CU are part of the tuning: every resident tile is 16 more write streams for
     // the memory system.  4-byte keys alone are fastest at the 5 the registers allow, and so are
     // 8-byte keys alone; with a payload 4 beat 5 (2^30 uint64 + payload: 77.9 -> 76.5 ms), which
     // the 4-byte-key variant reaches through its registers and the 8-byte-key variant through
     // LDS that is requested at launch and never touched.
     constexpr size_t hold_back = (HAS_V && sizeof(K) == 8) ? 6144 : 0;
-    {
+    if (scanfree) {
+        const int after = (s->cur + 2) % 3;
+        const ScanFreeTables sf{s->group_tot[s->cur], s->counts[after], s->group_tot[after], s->digit_starts,
+                                s->publish};
+        // the workgroups that publish the group sums come first, rounded up to the number of XCDs
+        const uint32_t grid = g.num_tiles + (((g.num_tiles + kGroupTiles - 1u) / kGroupTiles + 1u + 7u) & ~7u);
         LaunchTimer t(s, 2, stream);
         if (a.fuse_next)
-            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true>), dim3(g.num_tiles), dim3(kBlock), hold_back, stream,
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true, true>), dim3(grid), dim3(kBlock), hold_back, stream,
                                kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
-                               a.next_bit, next_mask, next_counts, a.order_in, a.order_out);
+                               a.next_bit, next_mask, next_counts, a.order_in, a.order_out, sf);
         else
-            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false>), dim3(g.num_tiles), dim3(kBlock), hold_back, stream,
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false, true>), dim3(grid), dim3(kBlock), hold_back, stream,
                                kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
-                               0, 0u, static_cast<uint32_t*>(nullptr), a.order_in, a.order_out);
+                               0, 0u, static_cast<uint32_t*>(nullptr), a.order_in, a.order_out, sf);
+    } else {
+        {
+            LaunchTimer t(s, 1, stream);
+            hipLaunchKernelGGL(scan_rows_kernel, dim3(g.num_groups), dim3(kBlock), 0, stream, counts, s->offsets,
+                               s->group_sums, g.num_tiles, a.fuse_next ? next_counts : static_cast<uint32_t*>(nullptr),
+                               a.n, s->digit_starts);
+            if (g.num_groups > 1)
+                hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, stream, s->group_sums, g.num_groups,
+                                   a.n, s->digit_starts);
+        }
+        const ScanFreeTables sf{nullptr, nullptr, nullptr, nullptr, 0};
+        LaunchTimer t(s, 2, stream);
+        if (a.fuse_next)
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true, false>), dim3(g.num_tiles), dim3(kBlock), hold_back, stream,
+                               kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
+                               a.next_bit, next_mask, next_counts, a.order_in, a.order_out, sf);
+        else
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false, false>), dim3(g.num_tiles), dim3(kBlock), hold_back, stream,
+                               kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
+                               0, 0u, static_cast<uint32_t*>(nullptr), a.order_in, a.order_out, sf);
     }
+    s->tables_scanfree = scanfree;
     RADX_TRY(hipGetLastError());
     s->tables_n = a.n;
     s->chained = a.fuse_next;
@@ -1152,9 +1463,12 @@ int radx_hip_destroy(radx_hip_sorter* s) {
     return 0;
 }
 
-int radx_hip_tune(radx_hip_sorter* s, int fuse_histogram) {
+int radx_hip_tune(radx_hip_sorter* s, int flags) {
     if (!s) return bad_arg("sorter is NULL");
-    s->fuse = fuse_histogram != 0;
+    if (flags < 0 || flags > 15 || (flags & 12) == 12) return bad_arg("flags must be 0..11");
+    s->fuse = (flags & 1) != 0;
+    s->scan_kernels = (flags & 2) != 0;
+    s->publish = (flags & 4) ? 0 : (flags & 8) ? 2 : 1;
     s->chained = false;
     return 0;
 }
@@ -1390,9 +1704,11 @@ int radx_hip_copy_tables(radx_hip_sorter* s, uint64_t n, uint32_t* counts, uint3
     if (offsets) {
         std::vector<uint32_t> sums(static_cast<size_t>(g.num_groups) * kRadices);
         RADX_TRY(hipMemcpy(offsets, s->offsets, words * 4, hipMemcpyDeviceToHost));
-        RADX_TRY(hipMemcpy(sums.data(), s->group_sums, sums.size() * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < words; ++i)
-            offsets[i] += sums[(i % kRadices) * g.num_groups + i / kRadices / kScanBlocks];
+        if (!s->tables_scanfree) {  // scan kernels leave the table in two parts
+            RADX_TRY(hipMemcpy(sums.data(), s->group_sums, sums.size() * 4, hipMemcpyDeviceToHost));
+            for (size_t i = 0; i < words; ++i)
+                offsets[i] += sums[(i % kRadices) * g.num_groups + i / kRadices / kScanBlocks];
+        }
     }
     return 0;
 }

@@ -113,8 +113,13 @@ class Sorter:
         capi.check(capi.lib.radx_hip_set_key_order(self._h, {"unsigned": 0, "signed": 1, "float": 2}[kind],
                                                    1 if descending else 0))
 
-    def tune(self, fuse_histogram=True):
-        capi.check(capi.lib.radx_hip_tune(self._h, 1 if fuse_histogram else 0))
+    def tune(self, fuse_histogram=True, scan_kernels=False, publish="all"):
+        """fuse_histogram: scatter passes produce the next pass's histogram.  scan_kernels: run the
+        scan kernels even for inputs small enough for the scan-free passes.  publish (tests):
+        "none" - scan-free passes publish nothing, every tile workgroup sums the table itself;
+        "bases" - no group sums are published, the scanning workgroup sums the table itself."""
+        flags = (1 if fuse_histogram else 0) | (2 if scan_kernels else 0) | {"all": 0, "none": 4, "bases": 8}[publish]
+        capi.check(capi.lib.radx_hip_tune(self._h, flags))
 
     def geometry(self, n):
         """(keys per tile, number of tiles) for n elements; one workgroup per tile."""

@@ -74,20 +74,38 @@ def check_geometry(s, n, cfg):
         assert b.offset == min(g * tile, n) and b.limit == min((g + 1) * tile, n) and b.count == 1
 
 
-@pytest.mark.parametrize("fused", [False, True])
-@pytest.mark.parametrize("n", [1000, 4096, 3 * 4096 + 17, 70000, 16 * 4096 + 1, 300 * 4096 + 5, 1027 * 4096 + 99])
-def test_u32_every_pass_matches_oracle(device, n, fused):
-    """Histogram table, scanned offsets table and scattered output after EACH pass — with the
-    histogram kernel every pass, and with the histogram accumulated by the previous scatter.
-    The two largest sizes have more than 256 tiles, i.e. more than one scan workgroup: the
-    second-level scan kernel and the two-part offsets (within-group scan + group base) are
-    compared table for table with the reference's single-workgroup partition
-    (shaders-sdk/radix/partition.comp:29-68), 2 and 5 scan groups."""
+# The three ways a pass gets its tables: histogram kernel + scan kernels every pass; histogram
+# accumulated by the previous scatter + scan kernels; and scan-free (inputs of at most 8192 tiles
+# with the fused histogram: no scan kernel, every scatter workgroup derives its own bases).
+# "fused_self_sum" / "fused_scanner_self_sum" are the scan-free mode with its publishing workgroups
+# switched off (all of them / only those of the group sums): the tile workgroups, or the scanning
+# workgroup, then wait their bounded number of looks and sum the table themselves, the paths that
+# in normal operation are only a safety net.
+PASS_MODES = ["unfused", "fused_scan_kernels", "fused", "fused_self_sum", "fused_scanner_self_sum"]
+
+
+def set_mode(s, mode):
+    s.tune(fuse_histogram=mode != "unfused", scan_kernels=mode == "fused_scan_kernels",
+           publish={"fused_self_sum": "none", "fused_scanner_self_sum": "bases"}.get(mode, "all"))
+    return mode != "unfused"
+
+
+@pytest.mark.parametrize("mode", PASS_MODES)
+@pytest.mark.parametrize("n", [1000, 4096, 3 * 4096 + 17, 70000, 16 * 4096 + 1, 65 * 4096 + 3, 300 * 4096 + 5,
+                               1027 * 4096 + 99])
+def test_u32_every_pass_matches_oracle(device, n, mode):
+    """Histogram table, offsets table and scattered output after EACH pass, in all three modes.
+    With scan kernels the two largest sizes have more than 256 tiles, i.e. more than one scan
+    workgroup: the second-level scan kernel and the two-part offsets (within-group scan + group
+    base) are compared table for table with the reference's single-workgroup partition
+    (shaders-sdk/radix/partition.comp:29-68), 2 and 5 scan groups.  Scan-free, the sizes cover
+    1, 2, 5 and 17 row groups of 64 tiles (and a last group of one tile)."""
     import torch
     import radx_amd
     keys = make_keys("hash", n, 4, seed=11)
     cfg = oracle.engine_config(n, 4)
     s = radx_amd.Sorter(n, 4, 0)
+    fused = set_mode(s, mode)
     check_geometry(s, n, cfg)
     cur = to_dev(keys, device)
     nxt = torch.empty_like(cur)
@@ -109,9 +127,9 @@ def test_u32_every_pass_matches_oracle(device, n, fused):
     assert np.array_equal(host, np.sort(keys))
 
 
-@pytest.mark.parametrize("fused", [False, True])
+@pytest.mark.parametrize("mode", PASS_MODES)
 @pytest.mark.parametrize("n", [777, 2048, 5 * 2048 + 9, 9 * 2048 + 1, 300 * 2048 + 5])
-def test_u64_kv_every_pass_matches_oracle(device, n, fused):
+def test_u64_kv_every_pass_matches_oracle(device, n, mode):
     import torch
     import radx_amd
     keys = make_keys("few_distinct", n, 8, seed=13)
@@ -119,6 +137,7 @@ def test_u64_kv_every_pass_matches_oracle(device, n, fused):
     vals = np.arange(n, dtype=np.uint32)
     cfg = oracle.engine_config(n, 8)
     s = radx_amd.Sorter(n, 8, 4)
+    fused = set_mode(s, mode)
     check_geometry(s, n, cfg)
     ck, cv = to_dev(keys, device), to_dev(vals, device)
     nk, nv = torch.empty_like(ck), torch.empty_like(cv)
@@ -137,16 +156,44 @@ def test_u64_kv_every_pass_matches_oracle(device, n, fused):
     s.close()
 
 
-@pytest.mark.parametrize("dist", ["skewed", "all_equal", "sorted", "top_digit_only"])
-def test_fused_histogram_on_skewed_inputs(device, dist):
-    """Every scatter pass's accumulated next-pass histogram equals counting on its output, for
-    inputs whose digit runs are long (one run can fill whole destination blocks)."""
+def test_u64_passes_above_the_scan_free_limit(device):
+    """8193 tiles: one more than the scan-free mode takes, so the default (fused) mode runs the
+    scan kernels with 33 scan groups; the last scan-free size, 8192 tiles = 128 row groups, next to
+    it.  Tables and output of the first three passes against the oracle."""
     import torch
     import radx_amd
-    n = 40 * 4096 + 333
+    for tiles in (8192, 8193):
+        n = (tiles - 1) * 2048 + 77
+        keys = make_keys("hash", n, 8, seed=tiles)
+        cfg = oracle.engine_config(n, 8)
+        s = radx_amd.Sorter(n, 8, 0)
+        assert s.geometry(n)[1] == tiles
+        cur = to_dev(keys, device)
+        nxt = torch.empty_like(cur)
+        host = keys
+        for p in range(3):
+            s.run_pass_fused(cur, nxt, 4 * p, 4, 4 * (p + 1), 4, use_fused_counts=p > 0)
+            counts, offsets = s.tables(n)
+            c, part, out = oracle.one_pass(cfg, host, p)
+            assert np.array_equal(counts, c) and np.array_equal(offsets, part), "tables, pass %d" % p
+            assert np.array_equal(to_host(nxt, 8), out), "scattered keys, pass %d" % p
+            cur, nxt, host = nxt, cur, out
+        s.close()
+
+
+@pytest.mark.parametrize("scan_kernels", [False, True])
+@pytest.mark.parametrize("dist", ["skewed", "all_equal", "sorted", "top_digit_only"])
+def test_fused_histogram_on_skewed_inputs(device, dist, scan_kernels):
+    """Every scatter pass's accumulated next-pass histogram equals counting on its output, for
+    inputs whose digit runs are long (one run can fill whole destination blocks and cross row
+    groups), with scan kernels and scan-free."""
+    import torch
+    import radx_amd
+    n = 140 * 4096 + 333
     keys = make_keys(dist, n, 4, seed=17)
     cfg = oracle.engine_config(n, 4)
     s = radx_amd.Sorter(n, 4, 0)
+    s.tune(True, scan_kernels)
     cur = to_dev(keys, device)
     nxt = torch.empty_like(cur)
     host = keys
@@ -160,13 +207,13 @@ def test_fused_histogram_on_skewed_inputs(device, dist):
     s.close()
 
 
-@pytest.mark.parametrize("fuse", [False, True])
-def test_result_independent_of_tuning(device, fuse):
+@pytest.mark.parametrize("mode", PASS_MODES)
+def test_result_independent_of_tuning(device, mode):
     import radx_amd
     n = 300007
     keys = make_keys("uniform", n, 4, seed=8)
     s = radx_amd.Sorter(n, 4, 0)
-    s.tune(fuse)
+    set_mode(s, mode)
     assert np.array_equal(gpu_sort(device, keys, sorter=s), np.sort(keys))
     s.close()
 
@@ -451,8 +498,9 @@ def test_config4_u64_kv_properties(device, log2n):
 
 
 def test_sort_is_graph_capturable(device):
-    """radx_hip_sort only enqueues kernels (no allocation, memset, copy or synchronisation), so a
-    caller can capture it into a HIP graph and replay it on new contents of the same buffers."""
+    """radx_hip_sort only enqueues kernels and, for small inputs, one memset of its own tables (no
+    allocation, copy or synchronisation), so a caller can capture it into a HIP graph and replay
+    it on new contents of the same buffers."""
     import torch
     import radx_amd
     n = 200000 + 7
@@ -481,6 +529,7 @@ def test_profiling_for_a_long_time_without_reading(device):
     n = 300 * 4096 + 1  # 2 scan groups: 25 launches per sort
     keys = make_keys("uniform", n, 4, seed=3)
     s = radx_amd.Sorter(n, 4, 0)
+    s.tune(True, scan_kernels=True)
     s.profile(True)
     k = to_dev(keys, device)
     swap = torch.empty_like(k)

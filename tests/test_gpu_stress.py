@@ -45,7 +45,7 @@ def test_random_sorts(device, seed):
 
         s = radx_amd.Sorter(n, key_bytes, 4 if with_vals else 0)
         s.set_key_order(kind, descending)
-        s.tune(bool(rng.integers(0, 4)))  # mostly fused
+        s.tune(bool(rng.integers(0, 4)), scan_kernels=bool(rng.integers(0, 2)))  # mostly fused; scan-free or not
         k = to_dev(keys, device)
         swap = torch.empty_like(k)
         v = to_dev(vals, device) if with_vals else None
