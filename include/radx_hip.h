@@ -164,11 +164,19 @@ int radx_hip_pass_fused(radx_hip_sorter* s, const void* keys_in, void* keys_out,
 int radx_hip_set_key_order(radx_hip_sorter* s, int key_kind, int descending);
 
 /*
- * Tuning knob.  fuse_histogram (default 1): let every scatter pass of radx_hip_sort produce the
- * next pass's histogram; 0 runs the histogram kernel every pass.  The sorted result and the
- * tables do not depend on it.
+ * Tuning knobs, as a bit set (default 1).  The sorted result and the tables radx_hip_copy_tables
+ * returns do not depend on any of them.
+ *   bit 0  fuse the histogram: every scatter pass of a sort also produces the next pass's
+ *          histogram; clear, the histogram kernel runs every pass (three launches per pass, the
+ *          reference's counting -> partition -> scattering, radx_implement.inl:427-444).
+ *   bit 1  always run the scan kernels.  Clear (default), inputs of at most 8192 tiles sorted with
+ *          bit 0 set run scan-free: the partition step is done by a few extra workgroups inside
+ *          the scatter launch, one launch per pass.
+ *   bit 2 / bit 3 (tests; at most one of them)  scan-free passes publish nothing / no group sums,
+ *          which makes every tile workgroup / the scanning workgroup sum the table itself — the
+ *          bounded-wait fallbacks that normal runs never take.
  */
-int radx_hip_tune(radx_hip_sorter* s, int fuse_histogram);
+int radx_hip_tune(radx_hip_sorter* s, int flags);
 
 /*
  * Geometry of the engine for n elements, i.e. get_blocks_info

@@ -22,7 +22,7 @@ import radx_amd
 PEAK_GBPS = 8000.0
 
 
-def measure(log2n, kb, vb, budget_ms):
+def measure(log2n, kb, vb, budget_ms, scan_kernels=False):
     n = 1 << log2n
     dev = torch.device("cuda:0")
     k = torch.empty(n, dtype=torch.int32 if kb == 4 else torch.int64, device=dev)
@@ -32,6 +32,7 @@ def measure(log2n, kb, vb, budget_ms):
         v = torch.empty(n, dtype=torch.int32, device=dev)
         vswap = torch.empty_like(v)
     s = radx_amd.Sorter(n, kb, vb)
+    s.tune(True, scan_kernels=scan_kernels)
 
     def gen(seed):
         if kb == 4:
@@ -98,6 +99,7 @@ def main():
     ap.add_argument("--types", type=str, default="u32,u64kv")
     ap.add_argument("--budget-ms", type=float, default=150.0)
     ap.add_argument("--out", type=str, default="")
+    ap.add_argument("--scan-kernels", action="store_true", help="run the scan kernels at every size (no scan-free passes)")
     a = ap.parse_args()
     sizes = sorted(set(range(a.lo, a.hi + 1, a.step)) | {int(x) for x in a.extra.split(",") if x})
     rows = []
@@ -105,7 +107,8 @@ def main():
     for ty in a.types.split(","):
         kb, vb = {"u32": (4, 0), "u64kv": (8, 4), "u32kv": (4, 4), "u64": (8, 0)}[ty]
         for l in sizes:
-            r = measure(l, kb, vb, a.budget_ms)
+            r = measure(l, kb, vb, a.budget_ms, a.scan_kernels)
+            r["scan_kernels_forced"] = a.scan_kernels
             r["type"] = ty
             rows.append(r)
             print("%-6s  %5d  %8.4f  %8.2f  %8.1f%% | %7.1f  %12.1f  %10.1f  %9.1f%% | %d"
