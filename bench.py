@@ -57,6 +57,29 @@ def parse():
 
 
 RANK_ENV = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")
+# Set by this script's own launcher: rank 0 opens its store on a port the system picks and writes
+# the number here, the other ranks read it.  (A port probed by the launcher could be taken by
+# another process before rank 0 binds it.)
+PORT_FILE_ENV = "RADX_BENCH_PORT_FILE"
+
+
+def rendezvous_store(path, rank, world, timeout):
+    """The process group's store when this script launched the ranks itself."""
+    from torch.distributed import TCPStore
+    if rank == 0:
+        store = TCPStore("127.0.0.1", 0, world, is_master=True, timeout=timeout, wait_for_workers=False)
+        with open(path + ".tmp", "w") as f:
+            f.write(str(store.port))
+        os.replace(path + ".tmp", path)
+        return store
+    deadline = time.monotonic() + timeout.total_seconds()
+    while not os.path.exists(path):
+        if time.monotonic() > deadline:
+            raise RuntimeError("rank 0 never published its store's port in %s" % path)
+        time.sleep(0.05)
+    with open(path) as f:
+        port = int(f.read())
+    return TCPStore("127.0.0.1", port, world, is_master=False, timeout=timeout)
 
 
 def launch_plan(n_ranks, argv, port=None):
@@ -75,11 +98,14 @@ def launch_ranks(n_ranks, argv):
     """Start one child per rank (this process never initialises a GPU and never execs), relay rank
     0's stdout, wait for all, and return the worst exit status.  When a rank fails the others get
     a grace period to notice (their collectives error out) and are then terminated by PID."""
+    import tempfile
     cmd, envs = launch_plan(n_ranks, argv)
+    port_file = os.path.join(tempfile.mkdtemp(prefix="radx_bench_"), "port")
     procs = []
     for r, over in enumerate(envs):
         env = dict(os.environ)
         env.update(over)
+        env[PORT_FILE_ENV] = port_file
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # rank 0 owns stdout (the JSON line); the other ranks' stdout joins stderr
         procs.append(subprocess.Popen(cmd, env=env, stdout=None if r == 0 else sys.stderr))
@@ -107,6 +133,12 @@ def launch_ranks(n_ranks, argv):
                     procs[r].wait()
             live.clear()
         time.sleep(0.05)
+    try:
+        if os.path.exists(port_file):
+            os.remove(port_file)
+        os.rmdir(os.path.dirname(port_file))
+    except OSError:
+        pass
     return worst
 
 
@@ -250,10 +282,13 @@ def main():
         # a collective that does not complete within 4 minutes aborts the rank (and, through the
         # launcher, the run) instead of hanging the whole job
         limit = datetime.timedelta(seconds=240)
+        where = {}
+        if os.environ.get(PORT_FILE_ENV):  # our own launcher: no fixed port
+            where["store"] = rendezvous_store(os.environ[PORT_FILE_ENV], rank, world, limit)
         if args.backend == "nccl":
-            init_process_group(dev, rank=rank, world_size=world, timeout=limit)
+            init_process_group(dev, rank=rank, world_size=world, timeout=limit, **where)
         else:
-            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit)
+            dist.init_process_group("gloo", rank=rank, world_size=world, timeout=limit, **where)
     # the collectives of the N > 1 path: RCCL on device tensors, or (rehearsal) gloo through host copies
     coll = dist if args.backend == "nccl" else HostStagedCollectives(dist)
 

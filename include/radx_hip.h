@@ -90,6 +90,9 @@ int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals,
  * enqueues the same kernels as radx_hip_sort on `stream`.  All calls on one GPU share that GPU's
  * array: calls that overlap in time on the same GPU (two streams, two threads) race on it, so
  * serialise them (one stream, or events between streams).  Nothing carries over between calls.
+ * keys / keys_swap / vals / vals_swap must be memory of GPU `device`.  The first call on a GPU
+ * looks up that GPU's copy of the array (which makes the runtime load the code object there): make
+ * it outside stream capture; every later call only enqueues kernels and can be captured.
  */
 #define RADX_HIP_NOALLOC_MAX_N (1ull << 26)
 int radx_hip_sort_noalloc(int device, void* keys, void* keys_swap, void* vals, void* vals_swap,
@@ -201,6 +204,28 @@ int radx_hip_copy_tables(radx_hip_sorter* s, uint64_t n, uint32_t* counts, uint3
  * of the last pass, followed by n.  out[d+1]-out[d] = number of keys with digit d.
  */
 int radx_hip_digit_starts(radx_hip_sorter* s, uint32_t out[17], void* stream);
+
+/*
+ * The same 17 words, copied on `stream` without synchronising: dst is device memory (or pinned
+ * host memory) the caller reads in stream order — e.g. the send buffer of the all-gather with
+ * which the ranks of a multi-GPU sort tell each other their run lengths, so that the host waits
+ * once per sort instead of once for its own lengths and once for everybody's.
+ */
+int radx_hip_digit_starts_async(radx_hip_sorter* s, void* dst, void* stream);
+
+/*
+ * Device-side views of the tables of the last pass over n elements — the counterparts of
+ * InternalInterface::histogramBufferInfo / prefixScansBufferInfo (include/radx/radx_internal.hpp:25-28,
+ * 37-38; bindings 3 and 4 of the reference's shaders), valid until the next call on this sorter:
+ *   counts[g * 16 + r]   keys of tile g whose digit is r                         (counting.comp:45)
+ *   offsets[g * 16 + r]  first output index for digit r of tile g (partition.comp:26) — complete
+ *                        when *group_bases comes back NULL (scan-free passes); otherwise the
+ *                        scan kernels leave it in two parts and the index is
+ *                        offsets[g * 16 + r] + group_bases[r * ceil(tiles / T) + g / T], T = *tiles_per_group.
+ * Any out-pointer may be NULL.  No synchronisation: read them in stream order after the pass.
+ */
+int radx_hip_device_tables(radx_hip_sorter* s, uint64_t n, const uint32_t** counts, const uint32_t** offsets,
+                           const uint32_t** group_bases, uint32_t* tiles_per_group);
 
 /*
  * Per-kernel timing.  When enabled, every launch made through this sorter is bracketed by

@@ -38,6 +38,9 @@ SIGNATURES = {
     "radx_hip_geometry": (ctypes.c_int, [_vp, ctypes.c_uint64, _u32p, _u32p]),
     "radx_hip_copy_tables": (ctypes.c_int, [_vp, ctypes.c_uint64, _vp, _vp, _vp]),
     "radx_hip_digit_starts": (ctypes.c_int, [_vp, _u32p, _vp]),
+    "radx_hip_digit_starts_async": (ctypes.c_int, [_vp, _vp, _vp]),
+    "radx_hip_device_tables": (ctypes.c_int, [_vp, ctypes.c_uint64, ctypes.POINTER(_vp), ctypes.POINTER(_vp),
+                                              ctypes.POINTER(_vp), _u32p]),
     "radx_hip_profile": (ctypes.c_int, [_vp, ctypes.c_int]),
     "radx_hip_kernel_times": (ctypes.c_int, [_vp, ctypes.POINTER(ctypes.c_double), _u64p]),
     "radx_hip_indiction": (ctypes.c_int, [_vp, _vp, _vp, ctypes.c_uint64, ctypes.c_size_t, _vp]),

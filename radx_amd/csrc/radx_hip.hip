@@ -1241,7 +1241,12 @@ hipError_t harvest_timings(radx_hip_sorter* s, bool wait) {
     hipError_t first_error = hipSuccess;
     for (auto& t : s->pending) {
         hipError_t e = wait ? hipEventSynchronize(t.stop) : hipEventQuery(t.stop);
-        if (e == hipErrorNotReady) { s->pending[kept++] = t; continue; }
+        if (e == hipErrorNotReady) {
+            // the query's own "not ready" must not surface as a later launch's error; nothing else is cleared
+            if (hipPeekAtLastError() == hipErrorNotReady) (void)hipGetLastError();
+            s->pending[kept++] = t;
+            continue;
+        }
         float f = 0.f;
         if (e == hipSuccess) e = hipEventElapsedTime(&f, t.start, t.stop);
         if (e == hipSuccess) { s->ms[t.kind] += f; s->launches[t.kind] += 1; }
@@ -1249,7 +1254,6 @@ hipError_t harvest_timings(radx_hip_sorter* s, bool wait) {
         s->pool.push_back(t);
     }
     s->pending.resize(kept);
-    if (!wait) (void)hipGetLastError();  // a "not ready" answer must not surface as the next launch's error
     return first_error;
 }
 constexpr size_t kMaxPendingTimings = 1024;  // ~40 sorts' worth; beyond it finished ones are folded in
@@ -1268,8 +1272,6 @@ public:
         if (!active_) return;
         (void)hipEventRecord(t_.stop, stream_);
         s_->pending.push_back(t_);
-        // a caller that profiles for a long time without reading the times must not grow the list forever
-        if (s_->pending.size() >= kMaxPendingTimings) (void)harvest_timings(s_, s_->pending.size() >= 4 * kMaxPendingTimings);
     }
 private:
     radx_hip_sorter* s_;
@@ -1369,6 +1371,10 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
 }
 
 int run_pass(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
+    // A caller that profiles for a long time without reading the times must not grow the list
+    // forever.  Folded in here, in front of the pass's launches, so that a launch error of this
+    // pass is still there for the check behind them.
+    if (s->pending.size() >= kMaxPendingTimings) (void)harvest_timings(s, s->pending.size() >= 4 * kMaxPendingTimings);
     const bool has_v = s->value_bytes != 0;
     if (s->key_bytes == 4)
         return has_v ? run_pass_typed<uint32_t, true>(s, a, stream) : run_pass_typed<uint32_t, false>(s, a, stream);
@@ -1671,6 +1677,17 @@ int radx_hip_sort_noalloc(int device, void* keys, void* keys_swap, void* vals, v
     s.value_bytes = value_bytes;
     if (const int rc = check_buffers(&s, keys, keys_swap, vals, vals_swap, n)) return rc;
     if (n == 0) return 0;
+    // the tables used are `device`'s copy of the array: every buffer has to live on that GPU
+    const void* bufs[4] = {keys, keys_swap, vals, vals_swap};
+    for (const void* b : bufs) {
+        if (!b) continue;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, b) != hipSuccess) {
+            (void)hipGetLastError();
+            return bad_arg("buffer is not memory HIP knows (hipMalloc / hipHostMalloc)");
+        }
+        if (attr.type == hipMemoryTypeDevice && attr.device != device) return bad_arg("buffer lives on another GPU than `device`");
+    }
     DeviceGuard guard(device);
     RADX_TRY(guard.status());
     char* base = nullptr;
@@ -1719,6 +1736,27 @@ int radx_hip_digit_starts(radx_hip_sorter* s, uint32_t out[17], void* stream) {
     RADX_TRY(guard.status());
     RADX_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     RADX_TRY(hipMemcpy(out, s->digit_starts, (kRadices + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int radx_hip_digit_starts_async(radx_hip_sorter* s, void* dst, void* stream) {
+    if (!s || !dst) return bad_arg("NULL argument");
+    DeviceGuard guard(s->device);
+    RADX_TRY(guard.status());
+    RADX_TRY(hipMemcpyAsync(dst, s->digit_starts, (kRadices + 1) * sizeof(uint32_t), hipMemcpyDefault,
+                            static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+int radx_hip_device_tables(radx_hip_sorter* s, uint64_t n, const uint32_t** counts, const uint32_t** offsets,
+                           const uint32_t** group_bases, uint32_t* tiles_per_group) {
+    if (!s) return bad_arg("sorter is NULL");
+    if (n == 0 || n > s->max_n) return bad_arg("n out of range");
+    if (s->tables_n != n) return bad_arg("the scratch holds no tables for this n: the last pass ran on a different element count (or none ran)");
+    if (counts) *counts = s->counts[s->cur];
+    if (offsets) *offsets = s->offsets;
+    if (group_bases) *group_bases = s->tables_scanfree ? nullptr : s->group_sums;
+    if (tiles_per_group) *tiles_per_group = kScanBlocks;
     return 0;
 }
 

@@ -12,7 +12,9 @@ Per rank, with G = world size, b = log2 G and S = 16 / G sub-buckets per rank:
   1. split     one scatter pass on the top 4-bit digit d = (destination rank r, sub-bucket j), the
                16 runs written in (j, r) order into `work`: for every j the runs for all
                destination ranks are adjacent.
-  2. counts    all_gather of the 16 run lengths -> every rank knows what it will receive.
+  2. counts    all_gather of the 17 run starts, straight from the split's device table, and the
+               buffer capacity -> every rank knows what everybody receives.  Reading the gathered
+               matrix is the only point of a sort at which the host waits for the device.
   3. exchange  S all-to-all-v's, issued back to back on RCCL's stream: number j sends sub-bucket j
                of every destination rank and lands, grouped by source, in region j of `stage`.
                xGMI is point-to-point, each peer pair has its own link, so the exchange as a whole
@@ -98,13 +100,16 @@ class HipEngine:
         self.value_bytes = value_bytes
         self.sorter = Sorter(capacity, key_bytes, value_bytes, device)
 
-    def msd_split(self, src, dst, n, log2_ranks, vsrc=None, vdst=None):
+    def msd_split(self, src, dst, n, log2_ranks, starts_out, vsrc=None, vdst=None):
         """Stable partition of src[:n] (and the payloads vsrc[:n]) into dst[:n] (vdst[:n]) on the
-        top digit, runs in (sub-bucket, rank) order; returns the 16 run starts followed by n."""
-        if n == 0:  # a rank with nothing to contribute: 16 empty runs (the C ABI reports the same)
-            return np.zeros(17, dtype=np.uint32)
+        top digit, runs in (sub-bucket, rank) order.  The 16 run starts followed by n go to
+        starts_out[:17] (int32 tensor on the device, uint32 bit patterns) in stream order: the
+        host does not wait."""
+        if n == 0:  # a rank with nothing to contribute: 16 empty runs
+            starts_out[:17].zero_()
+            return
         self.sorter.msd_split(src, dst, log2_ranks, vsrc, vdst, n=n)
-        return self.sorter.digit_starts()
+        self.sorter.digit_starts_into(starts_out)
 
     def sort_bits(self, keys, swap, n, begin_bit, end_bit, vals=None, vswap=None):
         self.sorter.sort_bits(keys, swap, begin_bit, end_bit, vals, vswap, n=n)
@@ -154,6 +159,7 @@ class ShardedSorter:
         # reports the last sort's
         self.profile = profile
         self._marks = None
+        self.host_waits = 0  # times sort() made the host wait for the device (once per exchanged sort)
 
     @staticmethod
     def suggest_capacity(n_local, slack=0.05):
@@ -195,6 +201,13 @@ class ShardedSorter:
                     or self._vals_stage.device != vals.device):
                 self._vals_stage = torch.empty_like(vals)
             vals_stage = self._vals_stage
+        # Every buffer has to start 16-byte aligned (the kernels load 16 bytes at a time and the
+        # regions are placed at aligned offsets from the base).  Checked here, before the first
+        # collective: an engine error inside the exchange would leave the other ranks waiting.
+        for name, t in (("keys", keys), ("work", work), ("stage", stage), ("vals", vals),
+                        ("vals_work", vals_work), ("vals_stage", vals_stage)):
+            if t is not None and t.data_ptr() % 16:
+                raise ValueError("%s must start at a 16-byte aligned address" % name)
         # regions start 16-byte aligned in `stage`; with 4-byte payloads beside 8-byte keys that
         # means a multiple of 4 elements
         align = max(self.align, 4) if kv else self.align
@@ -206,24 +219,30 @@ class ShardedSorter:
                      "landed": [], "sorted": []}
             marks["start"].record()
 
-        # 1. stable split on the top digit: keys -> work, runs in (sub-bucket, destination rank) order
-        if kv:
-            starts = self.engine.msd_split(keys, work, n_local, b, vals, vals_work).astype(np.int64)
-        else:
-            starts = self.engine.msd_split(keys, work, n_local, b).astype(np.int64)
-        if marks:
-            marks["split"].record()
-        runs = np.diff(starts)  # 16 run lengths; starts[16] == n_local
-
-        # 2. every rank learns the whole [source][16] matrix of run lengths, and every rank's capacity
+        # 1. stable split on the top digit: keys -> work, runs in (sub-bucket, destination rank)
+        #    order; its 17 run starts stay on the device, followed by this rank's capacity
         capacity = min(keys.numel(), stage.numel())
         if kv:
             capacity = min(capacity, vals.numel(), vals_stage.numel())
-        mine = torch.tensor(np.append(runs, capacity), dtype=torch.int64, device=keys.device)
-        gathered = torch.empty(G * 17, dtype=torch.int64, device=keys.device)
+        mine = torch.empty(18, dtype=torch.int32, device=keys.device)
+        mine[17:].fill_(capacity - (1 << 32) if capacity >= (1 << 31) else capacity)  # uint32 bits
+        if kv:
+            self.engine.msd_split(keys, work, n_local, b, mine, vals, vals_work)
+        else:
+            self.engine.msd_split(keys, work, n_local, b, mine)
+        if marks:
+            marks["split"].record()
+
+        # 2. every rank learns every rank's run starts and capacity.  The copy of the gathered
+        #    matrix to the host is the one place where the host waits for the device.
+        gathered = torch.empty(G * 18, dtype=torch.int32, device=keys.device)
         self.dist.all_gather_into_tensor(gathered, mine, group=self.group)
-        gathered = gathered.cpu().numpy().reshape(G, 17)
-        matrix, capacities = gathered[:, :16], gathered[:, 16]
+        gathered = gathered.cpu().numpy().view(np.uint32).astype(np.int64).reshape(G, 18)
+        self.host_waits += 1
+        all_starts, capacities = gathered[:, :17], gathered[:, 17]
+        matrix = np.diff(all_starts, axis=1)   # [source][16] run lengths
+        starts = all_starts[self.rank]          # starts[16] == n_local
+        runs = matrix[self.rank]
         # Every rank checks every rank's shard against that rank's buffers, so that all of them
         # raise together instead of one leaving the others waiting in the exchange.
         shard_lens = matrix.reshape(G, S, G).sum(axis=(0, 1))       # [destination rank]

@@ -137,6 +137,21 @@ class Sorter:
                                                  _stream(stream, self.device)))
         return counts, offsets
 
+    def digit_starts_into(self, dst, stream=None):
+        """The 17 run starts of the last pass copied into dst[:17] (a 4-byte-element tensor, device
+        or pinned host) in stream order; no synchronisation."""
+        if dst.element_size() != 4 or dst.numel() < 17 or not dst.is_contiguous():
+            raise ValueError("dst must be a contiguous tensor of at least 17 4-byte elements")
+        capi.check(capi.lib.radx_hip_digit_starts_async(self._h, _ptr(dst), _stream(stream, self.device)))
+
+    def device_tables(self, n):
+        """Device addresses (counts, offsets, group_bases or None, tiles_per_group) of the last pass's tables."""
+        c, o, gb = ctypes.c_void_p(None), ctypes.c_void_p(None), ctypes.c_void_p(None)
+        t = ctypes.c_uint32(0)
+        capi.check(capi.lib.radx_hip_device_tables(self._h, int(n), ctypes.byref(c), ctypes.byref(o), ctypes.byref(gb),
+                                                   ctypes.byref(t)))
+        return c.value, o.value, gb.value, t.value
+
     def digit_starts(self, stream=None):
         out = (ctypes.c_uint32 * 17)()
         capi.check(capi.lib.radx_hip_digit_starts(self._h, out, _stream(stream, self.device)))
@@ -160,6 +175,14 @@ def sort_noalloc(keys, swap, vals=None, vals_swap=None, n=None, stream=None):
     for t, name in ((keys, "keys"), (swap, "swap"), (vals, "vals"), (vals_swap, "vals_swap")):
         if t is not None and (not t.is_cuda or not t.is_contiguous() or t.numel() < n):
             raise ValueError("%s must be a contiguous device tensor of at least n elements" % name)
+        if t is not None and t.device != keys.device:
+            raise ValueError("%s is on %s, keys on %s" % (name, t.device, keys.device))
+    if keys.element_size() not in (4, 8) or swap.dtype != keys.dtype:
+        raise ValueError("keys must have 4- or 8-byte elements and swap the same dtype")
+    if (vals is None) != (vals_swap is None):
+        raise ValueError("vals and vals_swap go together")
+    if vals is not None and (vals.element_size() != 4 or vals_swap.dtype != vals.dtype):
+        raise ValueError("vals must have 4-byte elements and vals_swap the same dtype")
     device = keys.device.index if keys.device.index is not None else 0
     capi.check(capi.lib.radx_hip_sort_noalloc(device, _ptr(keys), _ptr(swap), _ptr(vals), _ptr(vals_swap), n,
                                               keys.element_size(), 0 if vals is None else 4,

@@ -53,3 +53,5 @@ def run_sharded(*args):
 def test_sharded_harness_plain_path(device):
     line = run_sharded("--gpus", "1", "--log2n", "20", "--iters", "1")
     assert line["pass"] is True and line["exchange"] is False
+    line = run_sharded("--gpus", "1", "--log2n", "18", "--iters", "1", "--type", "u64kv")
+    assert line["pass"] is True and line["type"] == "u64kv"

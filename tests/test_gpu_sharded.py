@@ -112,6 +112,14 @@ def test_sort_bits_into_may_pack_into_its_own_swap_buffer(device):
     s.close()
 
 
+def split_starts(eng, src, dst, n, log2_ranks):
+    """HipEngine.msd_split leaves its 17 run starts on the device; here they are read back."""
+    import torch
+    out = torch.full((17,), -1, dtype=torch.int32, device=src.device)
+    eng.msd_split(src, dst, n, log2_ranks, out)
+    return out.cpu().numpy().view(np.uint32).astype(np.int64)
+
+
 class ReplayDist:
     """Stands in for torch.distributed from ONE rank's point of view: the other ranks' split
     outputs were computed beforehand on the same GPU, and each all-to-all-v is replayed by
@@ -133,11 +141,10 @@ class ReplayDist:
 
     def all_gather_into_tensor(self, out, mine, group=None):
         import torch
-        runs = np.stack([np.diff(st) for st in self.starts])
-        mine = mine.cpu().numpy()
-        assert np.array_equal(mine[:16], runs[self.rank])
-        rows = np.concatenate([runs, np.full((self.world, 1), mine[16])], axis=1)  # same capacity everywhere
-        out.copy_(torch.from_numpy(rows.reshape(-1)).to(out.device))
+        mine = mine.cpu().numpy().view(np.uint32).astype(np.int64)   # 17 run starts + capacity
+        assert np.array_equal(mine[:17], self.starts[self.rank])
+        rows = np.concatenate([np.stack(self.starts), np.full((self.world, 1), mine[17])], axis=1)  # same capacity everywhere
+        out.copy_(torch.from_numpy(rows.astype(np.uint32).view(np.int32).reshape(-1)).to(out.device))
 
     def all_to_all_single(self, out, inp, output_split_sizes, input_split_sizes, group=None, async_op=False):
         j, G = self.calls, self.world
@@ -175,7 +182,7 @@ def test_sharded_sorter_every_rank_replayed(device, world, key_bytes, dist_name)
     for r in range(world):
         src = to_dev(inputs[r], device)
         dst = torch.empty_like(src)
-        starts.append(eng.msd_split(src, dst, n_local, b).astype(np.int64))
+        starts.append(split_starts(eng, src, dst, n_local, b))
         split_bufs.append(dst)
     tdt = torch.int32 if key_bytes == 4 else torch.int64
     whole = []
@@ -190,6 +197,7 @@ def test_sharded_sorter_every_rank_replayed(device, world, key_bytes, dist_name)
         shard, total, send, recv = sharder.sort(keys, work, n_local)
         torch.cuda.synchronize()
         assert fake.calls == 16 // world
+        assert sharder.host_waits == 1     # the gathered run starts; nothing else makes the host wait
         got = to_host(shard, key_bytes).copy()
         assert got.size == total == int(recv.sum()) and int(send.sum()) == n_local
         if b:
@@ -237,7 +245,7 @@ def test_sharded_sorter_with_an_empty_rank(device, empty_rank):
     for r in range(world):
         src = to_dev(inputs[r], device) if sizes[r] else torch.empty(4, dtype=torch.int32, device=device)
         dst = torch.empty_like(src)
-        starts.append(eng.msd_split(src, dst, sizes[r], b).astype(np.int64))
+        starts.append(split_starts(eng, src, dst, sizes[r], b))
         split_bufs.append(dst)
     assert not starts[empty_rank].any()
     whole = []
@@ -275,7 +283,7 @@ def test_sharded_sorter_follows_key_order(device, kind, descending):
     for r in range(world):
         src = to_dev(inputs[r], device)
         dst = torch.empty_like(src)
-        starts.append(eng.msd_split(src, dst, n_local, 2).astype(np.int64))
+        starts.append(split_starts(eng, src, dst, n_local, 2))
         split_bufs.append(dst)
     whole = []
     for r in range(world):

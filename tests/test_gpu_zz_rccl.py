@@ -71,3 +71,14 @@ def test_sharded_harness_one_gpu_through_rccl(device, log2n):
     per-region passes on their own stream; checked for full equality with std::sort."""
     line = run_sharded("--gpus", "1", "--log2n", log2n, "--iters", "2", "--force-exchange")
     assert line["pass"] is True and line["exchange"] is True and line["full_equality_checked"] is True
+    assert line["host_waits_per_sort"] == 1.0
+
+
+@pytest.mark.parametrize("log2n", ["15", "21"])
+def test_sharded_harness_key_value_globally_stable(device, log2n):
+    """uint64 keys + uint32 payloads through radx::ShardedSort: the payloads ride through the
+    split, a second grouped send/recv per sub-bucket and the local passes; keys (thinned, so ties
+    occur) and payloads equal std::stable_sort of the input — global stability."""
+    line = run_sharded("--gpus", "1", "--log2n", log2n, "--iters", "1", "--force-exchange", "--type", "u64kv")
+    assert line["pass"] is True and line["exchange"] is True and line["full_equality_checked"] is True
+    assert line["type"] == "u64kv" and line["host_waits_per_sort"] == 1.0

@@ -27,7 +27,7 @@ class OracleEngine:
     def _u(self, t, n):
         return t[:n].numpy().view(self.udt)
 
-    def msd_split(self, src, dst, n, log2_ranks, vsrc=None, vdst=None):
+    def msd_split(self, src, dst, n, log2_ranks, starts_out, vsrc=None, vdst=None):
         k = self._u(src, n)
         d = (k >> self.udt(self.bits - 4)).astype(np.uint32)
         # bucket (rank r, sub-bucket j), d = r * S + j, goes to position p = j * G + r
@@ -42,7 +42,7 @@ class OracleEngine:
         dst[:n] = torch.from_numpy(k[order].view(self.sdt).copy())
         if vsrc is not None:
             vdst[:n] = vsrc[:n][torch.from_numpy(order)]
-        return np.concatenate([parts[0], [n]]).astype(np.uint32)
+        starts_out[:17] = torch.from_numpy(np.concatenate([parts[0], [n]]).astype(np.uint32).view(np.int32))
 
     def _order_on(self, k, begin_bit, end_bit):
         field = (k >> self.udt(begin_bit)) & self.udt((1 << (end_bit - begin_bit)) - 1)

@@ -100,3 +100,49 @@ def test_at_the_limit(device):
     s.close()
     assert radx_amd.check_sorted(k) == 0 and radx_amd.checksum(k) == before
     assert bool(torch.equal(k, ref))
+
+
+def test_two_calls_captured_in_one_graph(device):
+    """Callers under HIP graph capture are who the entry point is for: two calls (the second on a
+    smaller input, a different key width and with a payload) captured into one graph after a first
+    call outside capture, replayed on new buffer contents and compared with numpy."""
+    import torch
+    import radx_amd
+    n1, n2 = 70 * 4096 + 9, 11 * 2048 + 3
+    k1 = torch.zeros(n1, dtype=torch.int32, device=device)
+    s1 = torch.empty_like(k1)
+    k2 = torch.zeros(n2, dtype=torch.int64, device=device)
+    s2 = torch.empty_like(k2)
+    v2 = torch.zeros(n2, dtype=torch.int32, device=device)
+    w2 = torch.empty_like(v2)
+    radx_amd.sort_noalloc(k1, s1)          # first call on this GPU: outside capture
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        radx_amd.sort_noalloc(k1, s1)
+        radx_amd.sort_noalloc(k2, s2, v2, w2)
+    for seed in (1, 2):
+        a = make_keys("uniform", n1, 4, seed=seed)
+        b = make_keys("few_distinct", n2, 8, seed=seed)
+        k1.copy_(to_dev(a, device))
+        k2.copy_(to_dev(b, device))
+        v2.copy_(torch.arange(n2, dtype=torch.int32, device=device))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(k1.cpu().numpy().view(np.uint32), np.sort(a))
+        order = np.argsort(b, kind="stable")
+        assert np.array_equal(k2.cpu().numpy().view(np.uint64), b[order])
+        assert np.array_equal(v2.cpu().numpy().view(np.uint32), order.astype(np.uint32))
+
+
+def test_wrapper_rejects_mismatched_tensors(device):
+    import torch
+    import radx_amd
+    k = torch.zeros(64, dtype=torch.int32, device=device)
+    with pytest.raises(ValueError):
+        radx_amd.sort_noalloc(k, torch.zeros(64, dtype=torch.int64, device=device))            # swap dtype
+    with pytest.raises(ValueError):
+        radx_amd.sort_noalloc(k, torch.zeros_like(k), torch.zeros(64, dtype=torch.int64, device=device),
+                              torch.zeros(64, dtype=torch.int64, device=device))               # 8-byte payload
+    with pytest.raises(ValueError):
+        radx_amd.sort_noalloc(k, torch.zeros_like(k), torch.zeros_like(k), None)               # half a payload
