@@ -39,6 +39,20 @@ $(SHARDED): harness/sharded_test.cpp $(LIB) $(wildcard include/radx/*.hpp) inclu
 	    -Lradx_amd/lib -lradx_hip -L/opt/rocm/lib -lamdhip64 -lrccl \
 	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,/opt/rocm/lib
 
+# Host-side sanitizer builds (test infrastructure): the oracle + CPU comparator behind a driver
+# that runs every geometry and edge size on exact-size heap buffers, and the harness (its
+# --cpu-only leg touches no GPU).  tests/test_sanitizers.py runs both and fails on any report.
+SANFLAGS := -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -g -O1
+asan: oracle/asan_driver harness/sort_test_asan
+oracle/asan_driver: oracle/asan_driver.cpp oracle/radx_oracle.c oracle/radx_oracle.h oracle/cpu_sort.cpp
+	$(CC) $(SANFLAGS) -std=c11 -Wall -Wextra -c -o oracle/radx_oracle_asan.o oracle/radx_oracle.c
+	$(CXX) $(SANFLAGS) -std=c++17 -fopenmp -Wall -Ioracle -o $@ oracle/asan_driver.cpp oracle/cpu_sort.cpp oracle/radx_oracle_asan.o
+harness/sort_test_asan: harness/sort_test.cpp $(LIB) $(wildcard include/radx/*.hpp) include/radx_hip.h
+	$(CXX) $(SANFLAGS) -std=c++17 -fopenmp -Wall -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
+	    -o $@ harness/sort_test.cpp \
+	    -Lradx_amd/lib -lradx_hip -L/opt/rocm/lib -lamdhip64 \
+	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,/opt/rocm/lib
+
 resources:
 	$(HIPCC) $(HIPFLAGS) -Rpass-analysis=kernel-resource-usage -c -o /dev/null radx_amd/csrc/radx_hip.hip 2>&1 | \
 	    grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" | grep -v "^$$" || true
@@ -51,6 +65,7 @@ tools/micro/copy_bench: tools/micro/copy_bench.hip
 	$(HIPCC) -O3 -w --offload-arch=$(ARCH) -o $@ $<
 
 clean:
-	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) $(SHARDED) tools/micro/copy_bench tools/micro/rocprim_sort_bench
+	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) $(SHARDED) tools/micro/copy_bench tools/micro/rocprim_sort_bench \
+	    oracle/asan_driver oracle/radx_oracle_asan.o harness/sort_test_asan
 
-.PHONY: all clean resources micro
+.PHONY: all clean resources micro asan
