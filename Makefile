@@ -12,8 +12,9 @@ ORACLE   := oracle/libradx_oracle.so
 CPUSORT  := oracle/libradx_cpusort.so
 HARNESS  := harness/sort_test
 SHARDED  := harness/sharded_test
+REFSEQ   := harness/reference_sequence
 
-all: $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) $(SHARDED)
+all: $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) $(SHARDED) $(REFSEQ)
 
 $(LIB): radx_amd/csrc/radx_hip.hip include/radx_hip.h
 	@mkdir -p radx_amd/lib
@@ -28,6 +29,13 @@ $(CPUSORT): oracle/cpu_sort.cpp
 $(HARNESS): harness/sort_test.cpp $(LIB) $(wildcard include/radx/*.hpp) include/radx_hip.h
 	$(CXX) -O2 -std=c++17 -fopenmp -Wall -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
 	    -o $@ harness/sort_test.cpp \
+	    -Lradx_amd/lib -lradx_hip -L/opt/rocm/lib -lamdhip64 \
+	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,/opt/rocm/lib
+
+# the reference harness's call sequence against these headers (compile check; on a GPU it also runs)
+$(REFSEQ): harness/reference_sequence.cpp $(LIB) $(wildcard include/radx/*.hpp) include/radx_hip.h
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude -I/opt/rocm/include -D__HIP_PLATFORM_AMD__ \
+	    -o $@ harness/reference_sequence.cpp \
 	    -Lradx_amd/lib -lradx_hip -L/opt/rocm/lib -lamdhip64 \
 	    -Wl,-rpath,'$$ORIGIN/../radx_amd/lib' -Wl,-rpath,/opt/rocm/lib
 
@@ -65,7 +73,7 @@ tools/micro/copy_bench: tools/micro/copy_bench.hip
 	$(HIPCC) -O3 -w --offload-arch=$(ARCH) -o $@ $<
 
 clean:
-	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) $(SHARDED) tools/micro/copy_bench tools/micro/rocprim_sort_bench \
+	rm -f $(LIB) $(ORACLE) $(CPUSORT) $(HARNESS) $(SHARDED) $(REFSEQ) tools/micro/copy_bench tools/micro/rocprim_sort_bench \
 	    oracle/asan_driver oracle/radx_oracle_asan.o harness/sort_test_asan
 
 .PHONY: all clean resources micro asan

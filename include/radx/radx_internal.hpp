@@ -32,18 +32,54 @@ namespace radx {
         InternalInterface(const std::shared_ptr<Device>& device) : device(device) {}
         InternalInterface(const InternalInterface&) = delete;
         InternalInterface& operator=(const InternalInterface&) = delete;
-        ~InternalInterface() { if (sorter) (void)radx_hip_destroy(sorter); }
+        virtual ~InternalInterface() { if (sorter) (void)radx_hip_destroy(sorter); }
 
-        InternalInterface& setMaxElementCount(const std::size_t& elementCount = 0) { maxElementCount = elementCount; return *this; }
+        // Views of the scratch tables (reference: radx_internal.hpp:25-28).  histogramBufferInfo and
+        // prefixScansBufferInfo are bindings 3 and 4 of the reference's shaders (counting.comp:45,
+        // partition.comp:26): device memory holding counts[tile][16] and partitions[tile][16] of
+        // the LAST pass of the last command(), refreshed by Radix::command (the engine rotates
+        // its tables, so the addresses change from sort to sort).  prefixScansBufferInfo is the
+        // complete table when prefixGroupBasesBufferInfo.buffer is null (inputs of up to 8192
+        // tiles); for larger inputs the scan kernels leave it in two parts, see
+        // radx_hip_device_tables.  The key staging views are the reference's 256-byte stubs
+        // (radx_implement.inl:463-471): nothing reads them, here as there.
+        DescriptorBufferInfo keysStoreBufferInfo{}, keysBackupBufferInfo{}, keysCacheBufferInfo{}, countMaximBufferInfo{},
+            histogramBufferInfo{}, prefixScansBufferInfo{}, prefixGroupBasesBufferInfo{};
+        virtual InternalInterface& setKeysStoreBufferInfo(const DescriptorBufferInfo& keysStore = {}) { keysStoreBufferInfo = keysStore; return *this; }
+        virtual InternalInterface& setKeysBackupBufferInfo(const DescriptorBufferInfo& keysBackup = {}) { keysBackupBufferInfo = keysBackup; return *this; }
+        virtual InternalInterface& setKeysCacheBufferInfo(const DescriptorBufferInfo& keysCache = {}) { keysCacheBufferInfo = keysCache; return *this; }
+        virtual InternalInterface& setCountMaximBufferInfo(const DescriptorBufferInfo& references = {}) { countMaximBufferInfo = references; return *this; }
+        virtual InternalInterface& setHistogramBufferInfo(const DescriptorBufferInfo& histogram = {}) { histogramBufferInfo = histogram; return *this; }
+        virtual InternalInterface& setPrefixScansBufferInfo(const DescriptorBufferInfo& prefixScans = {}) { prefixScansBufferInfo = prefixScans; return *this; }
+
+        // Points the table views at the tables of the last pass over n elements.
+        InternalInterface& refreshTableViews(std::size_t n) {
+            const uint32_t *counts = nullptr, *offsets = nullptr, *bases = nullptr;
+            uint32_t tilesPerGroup = 0, tile = 0, tiles = 0;
+            if (n == 0 || radx_hip_device_tables(sorter, n, &counts, &offsets, &bases, &tilesPerGroup) != 0) {
+                histogramBufferInfo = prefixScansBufferInfo = prefixGroupBasesBufferInfo = DescriptorBufferInfo();
+                return *this;
+            }
+            check_abi(radx_hip_geometry(sorter, n, &tile, &tiles));
+            const std::size_t bytes = static_cast<std::size_t>(tiles) * RADX_HIP_RADICES * sizeof(uint32_t);
+            histogramBufferInfo = DescriptorBufferInfo(const_cast<uint32_t*>(counts), 0, bytes);
+            prefixScansBufferInfo = DescriptorBufferInfo(const_cast<uint32_t*>(offsets), 0, bytes);
+            const std::size_t groups = (tiles + tilesPerGroup - 1) / tilesPerGroup;
+            prefixGroupBasesBufferInfo = bases ? DescriptorBufferInfo(const_cast<uint32_t*>(bases), 0, groups * RADX_HIP_RADICES * sizeof(uint32_t))
+                                               : DescriptorBufferInfo();
+            return *this;
+        }
+
+        virtual InternalInterface& setMaxElementCount(const std::size_t& elementCount = 0) { maxElementCount = elementCount; return *this; }
         // reference: buildMemory(memorySize) allocates the one scratch buffer (radx_internal.hpp:40)
-        InternalInterface& buildMemory(int keyBytes, int valueBytes) {
+        virtual InternalInterface& buildMemory(int keyBytes, int valueBytes) {
             if (sorter) { check_abi(radx_hip_destroy(sorter)); sorter = nullptr; }
             this->keyBytes = keyBytes; this->valueBytes = valueBytes;
             check_abi(radx_hip_create(device->ordinal(), maxElementCount, keyBytes, valueBytes, &sorter));
             return *this;
         }
         // No descriptor sets in HIP; kept so reference call sequences compile.
-        InternalInterface& buildDescriptorSet() { return *this; }
+        virtual InternalInterface& buildDescriptorSet() { return *this; }
 
         std::size_t getMaxElementCount() const { return maxElementCount; }
         std::size_t getMemorySize() const { return radx_hip_scratch_bytes(maxElementCount, keyBytes); }
@@ -62,6 +98,7 @@ namespace radx {
         friend class Algorithm;
         InputInterface() {}
         InputInterface(const std::shared_ptr<Device>& device) : device(device) {}
+        virtual ~InputInterface() {}
 
         DescriptorBufferInfo keysBufferInfo{}, swapBufferInfo{};
         // Payload that travels with its key: the binding the reference declares and never wires
@@ -69,15 +106,15 @@ namespace radx {
         DescriptorBufferInfo valuesBufferInfo{}, valuesSwapBufferInfo{};
         std::size_t elementCount = 0;
 
-        InputInterface& setKeysBufferInfo(const DescriptorBufferInfo& keys = {}) { keysBufferInfo = keys; built = false; return *this; }
-        InputInterface& setSwapBufferInfo(const DescriptorBufferInfo& swap = {}) { swapBufferInfo = swap; built = false; return *this; }
-        InputInterface& setValuesBufferInfo(const DescriptorBufferInfo& vals = {}) { valuesBufferInfo = vals; built = false; return *this; }
-        InputInterface& setValuesSwapBufferInfo(const DescriptorBufferInfo& swap = {}) { valuesSwapBufferInfo = swap; built = false; return *this; }
-        InputInterface& setElementCount(const std::size_t& elementCount = 0) { this->elementCount = elementCount; built = false; return *this; }
+        virtual InputInterface& setKeysBufferInfo(const DescriptorBufferInfo& keys = {}) { keysBufferInfo = keys; built = false; return *this; }
+        virtual InputInterface& setSwapBufferInfo(const DescriptorBufferInfo& swap = {}) { swapBufferInfo = swap; built = false; return *this; }
+        virtual InputInterface& setValuesBufferInfo(const DescriptorBufferInfo& vals = {}) { valuesBufferInfo = vals; built = false; return *this; }
+        virtual InputInterface& setValuesSwapBufferInfo(const DescriptorBufferInfo& swap = {}) { valuesSwapBufferInfo = swap; built = false; return *this; }
+        virtual InputInterface& setElementCount(const std::size_t& elementCount = 0) { this->elementCount = elementCount; built = false; return *this; }
 
         // reference: radx_implement.inl:357-388 creates buffer views and writes the descriptor set;
         // here it validates what the kernels assume about the views.
-        InputInterface& buildDescriptorSet() {
+        virtual InputInterface& buildDescriptorSet() {
             auto aligned = [](const DescriptorBufferInfo& b) { return (reinterpret_cast<std::uintptr_t>(b.address()) & 15u) == 0; };
             if (elementCount > 0) {
                 if (!keysBufferInfo.buffer || !swapBufferInfo.buffer)
@@ -129,6 +166,14 @@ namespace radx {
             return *this;
         }
 
+        // accepts only right-based links (reference: radx_internal.hpp:122-125)
+        virtual Sort<T>& initialize(const std::shared_ptr<Device>& device, std::shared_ptr<Algorithm>&& algorithm,
+                                    const std::size_t& maxElementCount = 1024 * 1024) {
+            std::shared_ptr<T> typed = std::dynamic_pointer_cast<T>(std::move(algorithm));
+            if (!typed) throw Error(static_cast<int>(hipErrorInvalidValue), "Sort::initialize: the algorithm is not of this Sort's type");
+            return this->initialize(device, typed, maxElementCount);
+        }
+
         // Enqueue the sort on cmdBuf's stream.  One sort in flight per Sort object.
         virtual Sort<T>& command(const CommandBuffer& cmdBuf, std::shared_ptr<InputInterface>& inputInterface) {
             Result res = SUCCESS;
@@ -137,6 +182,7 @@ namespace radx {
         }
 
         const InternalInterface& getInternalInterface() const { return *internalInterface; }
+        InternalInterface& getInternalInterface() { return *internalInterface; }
     };
 
     // reference: radx_internal.hpp:137-148, radx_implement.inl:391-490
@@ -165,6 +211,7 @@ namespace radx {
                                 inputInterface->swapBufferInfo.address(), inputInterface->valuesBufferInfo.address(),
                                 inputInterface->valuesSwapBufferInfo.address(), n, cmdBuf.stream);
             check_abi(res);
+            internalInterface->refreshTableViews(n);
             return res;
         }
 

@@ -69,3 +69,14 @@ def test_harness_cpu_path_config1():
         assert "Sorting Finished: PASS" in out.stdout
         line = json.loads(out.stdout.strip().splitlines()[-1])
         assert line["n"] == 1 << 20 and line["pass"] is True and line["threads"] >= 1
+
+
+def test_reference_call_sequence_compiles_against_these_headers():
+    """harness/reference_sequence.cpp is the reference harness's set-up and sort command
+    (src/test/sort.cpp:304-338,411) with only the handle types swapped, plus the overloads and
+    public members the reference declares and its own harness does not use.  Compiling it (no
+    GPU needed) is the test; tests/test_gpu_harness.py runs it."""
+    made = subprocess.run(["make", "-C", ROOT, "-W", "harness/reference_sequence.cpp", "harness/reference_sequence"], capture_output=True, text=True, timeout=600)
+    assert made.returncode == 0, made.stdout + made.stderr
+    assert "warning" not in made.stderr, made.stderr
+    assert os.access(os.path.join(ROOT, "harness", "reference_sequence"), os.X_OK)

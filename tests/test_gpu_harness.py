@@ -55,3 +55,12 @@ def test_sharded_harness_plain_path(device):
     assert line["pass"] is True and line["exchange"] is False
     line = run_sharded("--gpus", "1", "--log2n", "18", "--iters", "1", "--type", "u64kv")
     assert line["pass"] is True and line["type"] == "u64kv"
+
+
+def test_reference_call_sequence_runs(device):
+    """The transcription of the reference harness's own call sequence (compiled by the CPU test
+    suite): sorts 2^20 + 16 shuffled keys through Sort<Radix>::command and reads the histogram /
+    prefix-scan tables back through InternalInterface's public views."""
+    out = subprocess.run([os.path.join(ROOT, "harness", "reference_sequence")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Sorting Finished: PASS" in out.stdout
