@@ -66,7 +66,9 @@ resources:
 	    grep -E "Function Name|VGPRs:|SGPRs:|Occupancy|LDS Size|ScratchSize" | grep -v "^$$" || true
 
 # development micro-benchmark: HBM copy ceilings by access width and launch shape
-micro: tools/micro/copy_bench tools/micro/rocprim_sort_bench
+micro: tools/micro/copy_bench tools/micro/rocprim_sort_bench tools/micro/dispatch_bench
+tools/micro/dispatch_bench: tools/micro/dispatch_bench.hip
+	$(HIPCC) -O3 -w --offload-arch=$(ARCH) -o $@ $<
 tools/micro/rocprim_sort_bench: tools/micro/rocprim_sort_bench.hip
 	$(HIPCC) -O3 -w --offload-arch=$(ARCH) -o $@ $<
 tools/micro/copy_bench: tools/micro/copy_bench.hip

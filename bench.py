@@ -180,28 +180,35 @@ def other_configs(dev):
     import torch
     import radx_amd
     res = {}
-    for name, log2n, kb, vb, steps in (("2^28 uint32 keys", 28, 4, 0, 10),
-                                       ("2^30 uint64 keys + uint32 payload", 30, 8, 4, 3)):
+    for name, log2n, kb, vb, steps in (("2^23 uint32 keys", 23, 4, 0, 50),   # the reference harness's own size (src/test/sort.hpp:184)
+                                       ("2^28 uint32 keys", 28, 4, 0, 10),
+                                       ("2^30 uint64 keys + uint32 payload", 30, 8, 4, 3),
+                                       ("2^30 uint32 keys + uint32 payload", 30, 4, 4, 3),
+                                       ("2^30 uint64 keys", 30, 8, 0, 3)):
         n = 1 << log2n
         kdt = torch.int32 if kb == 4 else torch.int64
         keys = [torch.empty(n, dtype=kdt, device=dev) for _ in range(steps + 1)]
         vals = [torch.empty(n, dtype=torch.int32, device=dev) for _ in range(steps + 1)] if vb else None
         swap = torch.empty(n, dtype=kdt, device=dev)
         vswap = torch.empty(n, dtype=torch.int32, device=dev) if vb else None
-        for i, k in enumerate(keys):
+        index = torch.arange(n, dtype=torch.int32, device=dev) if kb == 4 and vb else None
+
+        def generate(i, seed):
             if kb == 4:
-                radx_amd.generate_u32(k, seed=1000 + i)
+                radx_amd.generate_u32(keys[i], seed=seed)
+                if vb:
+                    vals[i].copy_(index)  # payload = original index
             else:
-                radx_amd.generate_u64(k, vals[i], seed=1000 + i)
+                radx_amd.generate_u64(keys[i], vals[i] if vb else None, seed=seed)
+
+        for i in range(len(keys)):
+            generate(i, 1000 + i)
         s = radx_amd.Sorter(n, kb, vb)
         before = radx_amd.checksum(keys[steps])  # multiset of the last timed batch, before its sort
         # warm-up: a few sorts of a scratch batch (regenerated each time), at least ~50 ms of work,
         # so the timed sorts do not include the clock ramp after the idle gap of the set-up above
-        for w in range(3 if log2n >= 30 else 16):
-            if kb == 4:
-                radx_amd.generate_u32(keys[0], seed=500 + w)
-            else:
-                radx_amd.generate_u64(keys[0], vals[0], seed=500 + w)
+        for w in range(3 if log2n >= 30 else 16 if log2n >= 26 else 300):
+            generate(0, 500 + w)
             s.sort(keys[0], swap, vals[0] if vb else None, vswap)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -215,14 +222,30 @@ def other_configs(dev):
         if vb:
             # every payload still names the input slot its key came from: regenerate the batch
             # into the first slot and compare regenerated[payload[i]] with the sorted key i
-            radx_amd.generate_u64(keys[0], vals[0], seed=1000 + steps)
+            generate(0, 1000 + steps)
             ok = ok and bool(torch.equal(keys[0][vals[steps].long()], keys[steps]))
+        # per-launch kernel times of this shape: two more sorts of fresh batches with every launch
+        # bracketed by events; the dominant kernel is the scatter, one launch = one pass over n elements
+        s.profile(True)
+        for w in range(2 if log2n >= 28 else 10):
+            generate(0, 700 + w)
+            s.sort(keys[0], swap, vals[0] if vb else None, vswap)
+        kt = s.kernel_times()
+        s.profile(False)
+        per_launch = {k: round(v[0] / max(1, v[1]), 5) for k, v in kt.items()}
+        launch_bytes = 2.0 * (kb + vb) * n
+        scatter_ms = kt["scatter"][0] / max(1, kt["scatter"][1])
         bytes_per_elem = (kb * 2) * 2 * (kb + vb)  # passes x (read + write) x element bytes
         res[name] = {"ms_per_sort": round(dt * 1e3, 4), "G_elements_per_s": round(n / dt / 1e9, 3),
                      "algorithmic_bytes_per_element": bytes_per_elem,
-                     "frac_of_8TBps": round(n / dt * bytes_per_elem / 1e9 / PEAK_HBM_GBPS, 4), "verified": ok}
+                     "frac_of_8TBps": round(n / dt * bytes_per_elem / 1e9 / PEAK_HBM_GBPS, 4), "verified": ok,
+                     "kernels_ms_per_launch": per_launch,
+                     "launches_per_sort": {k: v[1] // (2 if log2n >= 28 else 10) for k, v in kt.items()},
+                     "scatter_roofline": {"algorithmic_bytes_per_launch": launch_bytes,
+                                          "achieved_GBps": round(launch_bytes / scatter_ms / 1e6, 1) if scatter_ms else 0.0,
+                                          "frac": round(launch_bytes / scatter_ms / 1e6 / PEAK_HBM_GBPS, 4) if scatter_ms else 0.0}}
         s.close()
-        del keys, vals, swap, vswap
+        del keys, vals, swap, vswap, index
         torch.cuda.empty_cache()
     return res
 
