@@ -83,7 +83,7 @@ int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals,
  * the reference (whose scratch is always a buffer allocated by Radix::createInternalMemory); it is
  * for callers that cannot call hipMalloc — code under HIP graph capture, tight serving loops,
  * harnesses that forbid allocation.  The histogram / prefix-scan tables live in a fixed device
- * array inside the library's code object (about 6 MiB, resident on every GPU the library is loaded
+ * array inside the library's code object (about 8 MiB, resident on every GPU the library is loaded
  * on until the process ends), so n is limited to RADX_HIP_NOALLOC_MAX_N elements; larger n fails
  * with hipErrorInvalidValue and a message.  Unsigned ascending order; key_bytes 4 or 8,
  * value_bytes 0 or 4, buffers as for radx_hip_sort.  The call makes no hipMalloc / hipFree and

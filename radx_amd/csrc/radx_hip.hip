@@ -228,7 +228,9 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
                                                        uint32_t num_tiles, int order_in,
                                                        uint32_t* __restrict__ zero_counts,
                                                        uint32_t* __restrict__ zero_groups_a,
-                                                       uint32_t* __restrict__ zero_groups_b) {
+                                                       uint32_t* __restrict__ zero_groups_b,
+                                                       uint32_t* __restrict__ zero_prefix_a,
+                                                       uint32_t* __restrict__ zero_prefix_b) {
     constexpr int KPT = KeyTraits<K>::kpt;
     constexpr uint32_t TILE = kBlock * KPT;
     constexpr int PER_VEC = 16 / sizeof(K);
@@ -286,8 +288,12 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
         counts[static_cast<size_t>(g) * kRadices + d] = lo;
         counts[static_cast<size_t>(g) * kRadices + d + 8u] = hi;
     }
-    // scan-free mode: the table the first scatter adds into, and the group sums of the first two passes
-    if (zero_counts && tid < static_cast<uint32_t>(kRadices)) zero_counts[static_cast<size_t>(g) * kRadices + tid] = 0u;
+    // scan-free mode: the table the first scatter adds into, and the published words of the first two passes
+    if (zero_counts && tid < static_cast<uint32_t>(kRadices)) {
+        zero_counts[static_cast<size_t>(g) * kRadices + tid] = 0u;
+        zero_prefix_a[static_cast<size_t>(g) * kRadices + tid] = 0u;
+        zero_prefix_b[static_cast<size_t>(g) * kRadices + tid] = 0u;
+    }
     if (zero_groups_a) {
         const uint32_t w = blockIdx.x * kBlock + tid;
         if (w < ((num_tiles + kGroupTiles - 1u) >> kLogGroupTiles) * kRadices) {
@@ -449,22 +455,24 @@ __global__ __launch_bounds__(1024) void scan_groups_kernel(uint32_t* __restrict_
 // What only the scan-free mode touches.
 struct ScanFreeTables {
     uint32_t* group_words;     // this pass's group sums and bases: cleared before the launch, published by its first workgroups
+    uint32_t* prefix_words;    // this pass's [tile][16] sums of the tile's own group in front of it, published likewise
     uint32_t* zero_counts;     // the table the pass after the next accumulates into: cleared row by row here
     uint32_t* zero_group_words;  // and the group words of the pass after the next
+    uint32_t* zero_prefix_words; // and its prefix words
     uint32_t* digit_starts;    // the 17 run starts
     int publish;               // tests only: 0 nothing is published, 2 only the bases are (1: everything)
 };
 
 // SCANLESS: no scan kernel runs for this pass; the scan is done by a few extra workgroups at the
 // front of the launch (their number rounded up to 8, which keeps the XCD of every tile workgroup).
-//   * Extra workgroup b < ceil(num_tiles / 64) sums the 16 columns of table rows [64 b, 64 b + 64)
-//     of `counts` and publishes the 16 sums.
+//   * Extra workgroup b < ceil(num_tiles / 64) scans the 16 columns of table rows [64 b, 64 b + 64)
+//     of `counts`: it publishes, for every one of its tiles, the 16 sums of the group's rows in
+//     front of that tile, and the 16 sums over the whole group.
 //   * The next extra workgroup waits for those sums, scans them in (digit, group) order and
 //     publishes, per group, the 16 output bases of the group's first tile (and the 17 run starts).
-//   * The workgroup of tile g reads the 16 bases of its group and the table rows of its own group
-//     in front of g (at most 63, one dword per lane and row, 16 lanes to a row), and stores its 16
-//     bases to offsets[g] (the reference's partitions[g][r], partition.comp:26) for readers of the
-//     tables.
+//   * The workgroup of tile g reads the 16 bases of its group and its own 16 in-group sums (two
+//     64-byte rows, by 16 lanes), adds them and stores its 16 bases to offsets[g] (the reference's
+//     partitions[g][r], partition.comp:26) for readers of the tables.
 // A published word carries bit 31 (the values stay below 2^26) and is written with one agent-scope
 // store and read with agent-scope loads: value and "is there" travel in one word, so no fences.
 // Tile workgroups look for their bases only after their keys are loaded and counted in LDS; the
@@ -526,25 +534,41 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
         const uint32_t b = blockIdx.x;
         if (b > num_grps || sf.publish == 0) return;
         if (b == num_grps && num_grps <= kOneLevelGroups) return;  // nobody reads the bases
-        if (b < num_grps) {  // the column sums of one group of table rows
-            if (sf.publish != 1) return;
-            uint32_t sum = 0;
+        if (b < num_grps) {
+            // One group of table rows.  Team t owns rows 4t .. 4t+3 of the group, lane c column c:
+            // exclusive scan down every column, then the column sums.
+            uint32_t c[kRowIters], mine = 0;
 #pragma unroll
             for (int i = 0; i < kRowIters; ++i) {
-                const uint32_t r = b * kGroupTiles + team + 16u * i;
-                if (r < num_tiles) sum += counts[static_cast<size_t>(r) * kRadices + tcol];
+                const uint32_t r = b * kGroupTiles + team * kRowIters + i;
+                c[i] = r < num_tiles ? counts[static_cast<size_t>(r) * kRadices + tcol] : 0u;
+                mine += c[i];
             }
-            sum += __shfl_xor(sum, 16, 64);
-            sum += __shfl_xor(sum, 32, 64);
-            if (lane < static_cast<uint32_t>(kRadices)) part_s[wave * kRadices + lane] = sum;
+            uint32_t incl = mine;  // over the teams of this wave
+            uint32_t up = __shfl_up(incl, 16, 64);
+            if (lane >= 16u) incl += up;
+            up = __shfl_up(incl, 32, 64);
+            if (lane >= 32u) incl += up;
+            if (lane >= 48u) part_s[wave * kRadices + tcol] = incl;
             __syncthreads();
-            if (tid < static_cast<uint32_t>(kRadices)) {
-                sum = 0;
+            uint32_t run = incl - mine, all = 0;
 #pragma unroll
-                for (int w = 0; w < kBlock / 64; ++w) sum += part_s[w * kRadices + tid];
-                __hip_atomic_store(&sf.group_words[b * kRadices + tid], sum | kGroupValid, __ATOMIC_RELAXED,
-                                   __HIP_MEMORY_SCOPE_AGENT);
+            for (int v = 0; v < kBlock / 64; ++v) {
+                const uint32_t t = part_s[v * kRadices + tcol];
+                if (static_cast<uint32_t>(v) < wave) run += t;
+                all += t;
             }
+#pragma unroll
+            for (int i = 0; i < kRowIters; ++i) {
+                const uint32_t r = b * kGroupTiles + team * kRowIters + i;
+                if (r < num_tiles)
+                    __hip_atomic_store(&sf.prefix_words[static_cast<size_t>(r) * kRadices + tcol], run | kGroupValid,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                run += c[i];
+            }
+            if (sf.publish == 1 && tid < static_cast<uint32_t>(kRadices))
+                __hip_atomic_store(&sf.group_words[b * kRadices + tid], all | kGroupValid, __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
             return;
         }
         // The scan over the groups.  Team t owns groups 8t .. 8t+7, lane c of a team column c.
@@ -565,10 +589,11 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             __builtin_amdgcn_s_sleep(16);
         }
         if (!have) {  // never in practice: the group sums straight from the table
-#pragma unroll 1
+#pragma unroll  // (w stays in registers only if every index into it is a constant)
             for (int i = 0; i < kGroupIters; ++i) {
                 const uint32_t r = team * kGroupIters + i;
                 uint32_t sum = 0;
+#pragma unroll 1
                 for (uint32_t t = r * kGroupTiles; t < min((r + 1u) * kGroupTiles, num_tiles); ++t)
                     sum += counts[static_cast<size_t>(t) * kRadices + tcol];
                 w[i] = sum;
@@ -618,12 +643,16 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
 
     // Global output base of every digit for this tile; issued first, consumed after the scan.
     uint32_t run_base = 0, run_len = 0;
-    const uint32_t my_grp = g >> kLogGroupTiles, in_grp = g & (kGroupTiles - 1u);
-    uint32_t base_word = kGroupValid, grp_word[SCANLESS ? kOneLevelIters : 1], row_word[SCANLESS ? kRowIters : 1];
+    const uint32_t my_grp = g >> kLogGroupTiles;
+    uint32_t base_word = kGroupValid, prefix_word = kGroupValid, grp_word[SCANLESS ? kOneLevelIters : 1];
     const bool one_level = num_grps <= kOneLevelGroups;
-    // One level: every team's group sums (rows past the end re-read the last one and are masked
-    // when summed).  Two levels: lanes 0..15 of wave 0 read the output bases of this tile's group.
+    // Lanes 0..15 of wave 0: the tile's sums over its own group's rows in front of it.  One level:
+    // every team's group sums as well (rows past the end re-read the last one and are masked when
+    // summed).  Two levels: lanes 0..15 of wave 0 also read the output bases of the tile's group.
     auto look_at_group_words = [&]() {
+        if (tid < static_cast<uint32_t>(kRadices))
+            prefix_word = __hip_atomic_load(&sf.prefix_words[static_cast<size_t>(g) * kRadices + tid], __ATOMIC_RELAXED,
+                                            __HIP_MEMORY_SCOPE_AGENT);
         if (one_level) {
 #pragma unroll
             for (int i = 0; i < kOneLevelIters; ++i) {
@@ -643,12 +672,6 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     if (SCANLESS) {
         if (tid == 0u) self_sum_s = 0u;
         if (!late_look) look_at_group_words();
-#pragma unroll
-        for (int i = 0; i < kRowIters; ++i) {
-            row_word[i] = 0u;
-            if (16u * i < in_grp)
-                row_word[i] = counts[static_cast<size_t>(my_grp * kGroupTiles + min(team + 16u * i, in_grp - 1u)) * kRadices + tcol];
-        }
         if (ALIGNED && tid < static_cast<uint32_t>(kRadices)) run_len = counts[static_cast<size_t>(g) * kRadices + tid];
     } else if (tid < static_cast<uint32_t>(kRadices)) {
         run_base = offsets[static_cast<size_t>(g) * kRadices + tid] +
@@ -727,11 +750,6 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
         }
     }
     if (!SCANLESS && ALIGNED && wave == 0u) place_runs();
-    uint32_t bef_rows = 0;  // SCANLESS: this team's share of the own group's rows in front of the tile
-    if (SCANLESS) {
-#pragma unroll
-        for (int i = 0; i < kRowIters; ++i) bef_rows += team + 16u * i < in_grp ? row_word[i] : 0u;
-    }
     __syncthreads();
 #pragma unroll
     for (int m = 0; m < NVEC; ++m) {
@@ -767,7 +785,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     if (SCANLESS) {
         if (one_level || wave == 0u) {
             for (int looks = 1;; ++looks) {
-                uint32_t there = base_word;
+                uint32_t there = base_word & prefix_word;
 #pragma unroll
                 for (int i = 0; i < kOneLevelIters; ++i) there &= one_level ? grp_word[i] : kGroupValid;
                 if (__all(static_cast<int>(there >> 31))) break;
@@ -776,9 +794,8 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
                 look_at_group_words();
             }
         }
-        // The rows of the tile's own group in front of it (and, one level, the group sums): every
-        // team's partial column sums, then the 4 teams of a wave.
-        uint32_t tot = 0, bef = bef_rows;
+        // One level: the group sums, every team's partial column sums, then the 4 teams of a wave.
+        uint32_t tot = 0, bef = 0;
         if (one_level) {
 #pragma unroll
             for (int i = 0; i < kOneLevelIters; ++i) {
@@ -823,10 +840,11 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             // the group's bases, or (having summed the table here) the digit starts: lanes past 15 add 0
             const uint32_t scanned = wave_inclusive_scan(tot) - tot;
             const uint32_t start = (one_level || self_sum_s) ? scanned : base_word & ~kGroupValid;
-            run_base = start + bef;
+            run_base = start + bef + (self_sum_s ? 0u : prefix_word & ~kGroupValid);
             if (lane < static_cast<uint32_t>(kRadices)) {
                 offsets[static_cast<size_t>(g) * kRadices + lane] = run_base;
                 sf.zero_counts[static_cast<size_t>(g) * kRadices + lane] = 0u;
+                sf.zero_prefix_words[static_cast<size_t>(g) * kRadices + lane] = 0u;
                 if (g < num_grps) {
                     sf.zero_group_words[g * kRadices + lane] = 0u;
                     sf.zero_group_words[kGroupBaseWords + g * kRadices + lane] = 0u;
@@ -924,7 +942,11 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             // slots hold (stale words) never passes this test, whatever digit it decodes to
             const bool live = ALIGNED ? (s - w[j].z) < w[j].w : (!guarded || s < valid);
             if (HAS_V) where[m0 + j] = ALIGNED && !live ? 0xffffffffu : at;
+#if defined(RADX_SAFE_STORES)  // development builds: a wrong output base shows up as a parity failure, not as a memory fault
+            if (live && at < n) kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];
+#else
             if (live) kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];  // last pass restores the key's own bits
+#endif
             if (FUSE) {
                 const uint32_t slot = (digit_of<K>(k[j], bit, mask) << 4) | digit_of<K>(k[j], next_bit, next_mask);
                 const bool in_first = at <= w[j].y;
@@ -984,8 +1006,13 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
         const uint32_t second_sum = next_second[tid];
         const uint32_t dest = where_s[tid >> 4].y >> LOG_TILE;
         uint32_t* row = next_counts + static_cast<size_t>(dest) * kRadices + (tid & 15u);
+#if defined(RADX_SAFE_STORES)
+        if (first_sum && dest < num_tiles) atomicAdd(row, first_sum);
+        if (second_sum && dest + 1u < num_tiles) atomicAdd(row + kRadices, second_sum);
+#else
         if (first_sum) atomicAdd(row, first_sum);
         if (second_sum) atomicAdd(row + kRadices, second_sum);
+#endif
     }
 
     if (HAS_V) {
@@ -996,7 +1023,11 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
 #pragma unroll
         for (int m = 0; m < NIT; ++m) {
             const uint32_t s = m * kBlock + tid;
+#if defined(RADX_SAFE_STORES)
+            if ((ALIGNED ? where[m] != 0xffffffffu : s < valid) && where[m] < n)
+#else
             if (ALIGNED ? where[m] != 0xffffffffu : s < valid)
+#endif
                 vout[where[m]] = stage[rank_slot<4>((m & 3) * kBlock + tid) + (m >> 2) * (4 * kBlock)];
         }
     }
@@ -1146,9 +1177,10 @@ constexpr size_t align256(size_t b) { return (b + 255u) & ~static_cast<size_t>(2
 
 // counts[0..1] alternate between "scanned this pass" and "accumulated for the next pass".  The
 // scan-free mode (at most kScanlessMaxTiles tiles) rotates through three tables, so counts[2]
-// only has that many rows, and keeps one small table of group sums beside each.
+// only has that many rows, and keeps one small table of group sums and one [tile][16] table of
+// published in-group prefixes beside each.
 struct ScratchLayout {
-    size_t counts[3], group_tot[3], offsets, group_sums, digit_starts, total;
+    size_t counts[3], group_tot[3], prefix_words[3], offsets, group_sums, digit_starts, total;
 };
 constexpr size_t kGroupTotBytes = align256(2 * kGroupBaseWords * 4);  // group sums, then group bases
 constexpr ScratchLayout layout_for(uint64_t max_n, int key_bytes) {
@@ -1163,6 +1195,7 @@ constexpr ScratchLayout layout_for(uint64_t max_n, int key_bytes) {
     l.counts[1] = at;    at += table;
     l.group_tot[2] = at; at += kGroupTotBytes;
     l.counts[2] = at;    at += align256(static_cast<size_t>(small_tiles) * kRadices * 4);
+    for (int i = 0; i < 3; ++i) { l.prefix_words[i] = at; at += align256(static_cast<size_t>(small_tiles) * kRadices * 4); }
     l.offsets = at;      at += table;
     l.group_sums = at;   at += align256(static_cast<size_t>(g.num_groups) * kRadices * 4);
     l.digit_starts = at; at += align256(32 * 4);
@@ -1204,6 +1237,7 @@ struct radx_hip_sorter {
     ScratchLayout layout{};
     uint32_t* counts[3] = {nullptr, nullptr, nullptr};
     uint32_t* group_tot[3] = {nullptr, nullptr, nullptr};
+    uint32_t* prefix_words[3] = {nullptr, nullptr, nullptr};
     bool tables_scanfree = false;  // the last pass ran scan-free: offsets holds full output bases
     uint32_t* offsets = nullptr;
     uint32_t* group_sums = nullptr;
@@ -1228,6 +1262,7 @@ void bind_scratch(radx_hip_sorter* s, char* base) {
     for (int i = 0; i < 3; ++i) {
         s->counts[i] = reinterpret_cast<uint32_t*>(base + s->layout.counts[i]);
         s->group_tot[i] = reinterpret_cast<uint32_t*>(base + s->layout.group_tot[i]);
+        s->prefix_words[i] = reinterpret_cast<uint32_t*>(base + s->layout.prefix_words[i]);
     }
     s->offsets = reinterpret_cast<uint32_t*>(base + s->layout.offsets);
     s->group_sums = reinterpret_cast<uint32_t*>(base + s->layout.group_sums);
@@ -1313,7 +1348,8 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
         // scan-free: it also clears the table the first scatter adds into and the group sums of the first two passes
         hipLaunchKernelGGL(hist_kernel<K>, dim3(g.num_tiles), dim3(kBlock), 0, stream, kin, a.n, a.bit,
                            mask, s->counts[0], g.num_tiles, a.order_in, scanfree ? s->counts[1] : none,
-                           scanfree ? s->group_tot[0] : none, scanfree ? s->group_tot[1] : none);
+                           scanfree ? s->group_tot[0] : none, scanfree ? s->group_tot[1] : none,
+                           scanfree ? s->prefix_words[0] : none, scanfree ? s->prefix_words[1] : none);
     }
     uint32_t* counts = s->counts[s->cur];
     const int next = scanfree ? (s->cur + 1) % 3 : s->cur ^ 1;
@@ -1326,8 +1362,8 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
     constexpr size_t hold_back = (HAS_V && sizeof(K) == 8) ? 6144 : 0;
     if (scanfree) {
         const int after = (s->cur + 2) % 3;
-        const ScanFreeTables sf{s->group_tot[s->cur], s->counts[after], s->group_tot[after], s->digit_starts,
-                                s->publish};
+        const ScanFreeTables sf{s->group_tot[s->cur], s->prefix_words[s->cur], s->counts[after], s->group_tot[after],
+                                s->prefix_words[after], s->digit_starts, s->publish};
         // the workgroups that publish the group sums come first, rounded up to the number of XCDs
         const uint32_t grid = g.num_tiles + (((g.num_tiles + kGroupTiles - 1u) / kGroupTiles + 1u + 7u) & ~7u);
         LaunchTimer t(s, 2, stream);
@@ -1349,7 +1385,7 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
                 hipLaunchKernelGGL(scan_groups_kernel, dim3(1), dim3(1024), 0, stream, s->group_sums, g.num_groups,
                                    a.n, s->digit_starts);
         }
-        const ScanFreeTables sf{nullptr, nullptr, nullptr, nullptr, 0};
+        const ScanFreeTables sf{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0};
         LaunchTimer t(s, 2, stream);
         if (a.fuse_next)
             hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true, false>), dim3(g.num_tiles), dim3(kBlock), hold_back, stream,
@@ -1632,7 +1668,7 @@ namespace {
 constexpr uint64_t kNoAllocMaxN = RADX_HIP_NOALLOC_MAX_N;
 constexpr size_t kNoAllocScratchBytes = layout_for(kNoAllocMaxN, 8).total;  // 8-byte keys have the smaller tile: more rows
 static_assert(layout_for(kNoAllocMaxN, 4).total <= kNoAllocScratchBytes, "the 4-byte-key layout must fit as well");
-static_assert(kNoAllocScratchBytes <= (8u << 20), "keep the resident array modest");
+static_assert(kNoAllocScratchBytes <= (9u << 20), "keep the resident array modest");
 constexpr int kMaxDevices = 64;
 }  // namespace
 
