@@ -423,6 +423,8 @@ def main():
     kt = engine.sorter.kernel_times()
     engine.sorter.profile(False)
     timeline = sharder.timeline() if multi else None
+    # how often a step made the host wait for the device: the gathered run starts, nothing else
+    host_waits_per_step = sharder.host_waits / float(W + K + P) if multi else None
 
     # device-to-device copy ceiling of this GPU, same run
     src, dst = pool[0], work
@@ -485,6 +487,7 @@ def main():
                                "all_to_all_calls_per_step": 16 // world,
                                "backend": "nccl (RCCL)" if args.backend == "nccl" else "gloo (rehearsal)",
                                "overlapped_with_local_passes": args.backend == "nccl",
+                               "host_waits_per_step": host_waits_per_step,
                                "last_step_timeline_ms_rank0": timeline}
         if extras is not None:
             out["other_configs"] = extras

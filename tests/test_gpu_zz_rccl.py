@@ -58,6 +58,7 @@ def test_bench_exchange_path_rehearsed(device):
     line = run_bench("--log2n", "22", "--steps", "2", "--warmup", "1", "--no-cpu", "--rehearse-exchange")
     check_contract(line, 2, 1)
     assert line["exchange"]["all_to_all_calls_per_step"] == 16
+    assert line["exchange"]["host_waits_per_step"] == 1.0   # the gathered run starts; nothing else blocks the host
     timeline = line["exchange"]["last_step_timeline_ms_rank0"]
     assert len(timeline["exchange_landed"]) == len(timeline["region_sorted"]) == 16
     assert 0 < timeline["split_done"] < timeline["region_sorted"][-1]
