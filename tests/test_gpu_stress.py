@@ -63,3 +63,36 @@ def test_random_sorts(device, seed):
         if with_vals:
             assert np.array_equal(to_host(v), vals[order]), what
         s.close()
+
+
+@pytest.mark.parametrize("key_bytes,with_vals,tiles,dist", [
+    (4, False, 2049, "skewed"), (4, True, 3000, "heavy"), (8, True, 2600, "few_distinct"),
+    (8, False, 5000, "sorted"), (4, False, 8192, "all_equal"), (8, True, 8192, "heavy"), (4, True, 4097, "top_digit_only")])
+def test_scan_free_sizes_with_many_row_groups(device, key_bytes, with_vals, tiles, dist):
+    """More than 32 groups of 64 table rows (above 2048 tiles): the scan-free passes then take
+    their output bases from the scanning workgroup.  Ragged sizes up to the last scan-free size
+    (8192 tiles), skewed and degenerate keys whose digit runs span many tiles and row groups,
+    against numpy's stable sort; once more with the scan kernels on the same input."""
+    import torch
+    import radx_amd
+    rng = np.random.default_rng(tiles)
+    tile = 4096 if key_bytes == 4 else 2048
+    n = (tiles - 1) * tile + int(rng.integers(1, tile + 1))
+    keys = skewed_keys(rng, n, key_bytes) if dist == "heavy" else make_keys(dist, n, key_bytes, seed=tiles)
+    vals = np.arange(n, dtype=np.uint32)
+    order = np.argsort(keys, kind="stable")
+    s = radx_amd.Sorter(n, key_bytes, 4 if with_vals else 0)
+    assert s.geometry(n)[1] == tiles
+    for scan_kernels in (False, True):
+        s.tune(True, scan_kernels=scan_kernels)
+        k = to_dev(keys, device)
+        swap = torch.empty_like(k)
+        v = to_dev(vals, device) if with_vals else None
+        vswap = torch.empty_like(v) if with_vals else None
+        s.sort(k, swap, v, vswap)
+        torch.cuda.synchronize()
+        assert np.array_equal(to_host(k, key_bytes), keys[order]), "scan kernels: %s" % scan_kernels
+        if with_vals:
+            assert np.array_equal(to_host(v), vals[order].astype(np.uint32)), "scan kernels: %s" % scan_kernels
+        del k, swap, v, vswap
+    s.close()
