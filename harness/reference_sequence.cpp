@@ -128,8 +128,45 @@ public:
             for (size_t i = 16; i < words && pass; ++i) pass = prefix[i] == prefix[i - 16] + counts[i - 16];
         }
         radx::check_hip(hipStreamDestroy(stream), "hipStreamDestroy");
+        pass = pass && twoPartTables();
         std::printf("Sorting Finished: %s\n", pass ? "PASS" : "FAIL");
         return pass ? 0 : 1;
+    }
+
+    // Above 8192 tiles the scan kernels leave the prefix table in two parts: the same check of
+    // partitions[g][r] through prefixScansBufferInfo + prefixGroupBasesBufferInfo.
+    bool twoPartTables() {
+        const size_t n = size_t(8200) * 4096 + 5;   // 8201 tiles
+        auto sorter = std::make_shared<OpenSort>();
+        sorter->initialize(device, program, n);
+        auto buffer = std::make_shared<radx::VmaAllocatedBuffer>(device, 2 * (n + 3) * sizeof(uint32_t), 0, radx::MEMORY_USAGE_GPU_ONLY);
+        const size_t swapOffset = ((n * sizeof(uint32_t) + 15) / 16) * 16;
+        radx::Vector<uint32_t> keys(buffer, n, 0), swap(buffer, n, swapOffset);
+        radx::check_abi(radx_hip_generate_u32(keys.deviceData(), n, 11, nullptr));
+        auto input = std::make_shared<radx::InputInterface>(device);
+        input->setElementCount(n).setKeysBufferInfo(keys).setSwapBufferInfo(swap).buildDescriptorSet();
+        sorter->command(radx::CommandBuffer(nullptr), input);
+        radx::check_hip(hipDeviceSynchronize(), "sync");
+        uint64_t bad = 1;
+        radx::check_abi(radx_hip_check_sorted(keys.deviceData(), nullptr, n, 4, &bad, nullptr));
+        radx::InternalInterface& internal = sorter->internal();
+        const size_t words = internal.histogramBufferInfo.range / sizeof(uint32_t), tiles = words / 16;
+        if (bad || tiles != 8201 || !internal.prefixGroupBasesBufferInfo.buffer || !internal.prefixTilesPerGroup) return false;
+        const size_t groups = internal.prefixGroupBasesBufferInfo.range / (16 * sizeof(uint32_t));
+        const size_t tilesPerGroup = internal.prefixTilesPerGroup;
+        std::vector<uint32_t> counts(words), prefix(words), bases(groups * 16);
+        radx::check_hip(hipMemcpy(counts.data(), internal.histogramBufferInfo.address(), words * 4, hipMemcpyDeviceToHost), "counts");
+        radx::check_hip(hipMemcpy(prefix.data(), internal.prefixScansBufferInfo.address(), words * 4, hipMemcpyDeviceToHost), "prefix");
+        radx::check_hip(hipMemcpy(bases.data(), internal.prefixGroupBasesBufferInfo.address(), bases.size() * 4, hipMemcpyDeviceToHost), "bases");
+        // partitions[g][r] in (digit, tile) order is the running sum of counts      partition.comp:29-68
+        uint64_t run = 0;
+        for (int r = 0; r < 16; ++r)
+            for (size_t g = 0; g < tiles; ++g) {
+                const uint64_t have = uint64_t(prefix[g * 16 + r]) + bases[size_t(r) * groups + g / tilesPerGroup];
+                if (have != run) return false;
+                run += counts[g * 16 + r];
+            }
+        return run == n;
     }
 };
 

@@ -45,6 +45,7 @@ namespace radx {
         // (radx_implement.inl:463-471): nothing reads them, here as there.
         DescriptorBufferInfo keysStoreBufferInfo{}, keysBackupBufferInfo{}, keysCacheBufferInfo{}, countMaximBufferInfo{},
             histogramBufferInfo{}, prefixScansBufferInfo{}, prefixGroupBasesBufferInfo{};
+        std::size_t prefixTilesPerGroup = 0;  // tiles that share one row of prefixGroupBasesBufferInfo
         virtual InternalInterface& setKeysStoreBufferInfo(const DescriptorBufferInfo& keysStore = {}) { keysStoreBufferInfo = keysStore; return *this; }
         virtual InternalInterface& setKeysBackupBufferInfo(const DescriptorBufferInfo& keysBackup = {}) { keysBackupBufferInfo = keysBackup; return *this; }
         virtual InternalInterface& setKeysCacheBufferInfo(const DescriptorBufferInfo& keysCache = {}) { keysCacheBufferInfo = keysCache; return *this; }
@@ -64,6 +65,7 @@ namespace radx {
             const std::size_t bytes = static_cast<std::size_t>(tiles) * RADX_HIP_RADICES * sizeof(uint32_t);
             histogramBufferInfo = DescriptorBufferInfo(const_cast<uint32_t*>(counts), 0, bytes);
             prefixScansBufferInfo = DescriptorBufferInfo(const_cast<uint32_t*>(offsets), 0, bytes);
+            prefixTilesPerGroup = tilesPerGroup;
             const std::size_t groups = (tiles + tilesPerGroup - 1) / tilesPerGroup;
             prefixGroupBasesBufferInfo = bases ? DescriptorBufferInfo(const_cast<uint32_t*>(bases), 0, groups * RADX_HIP_RADICES * sizeof(uint32_t))
                                                : DescriptorBufferInfo();
