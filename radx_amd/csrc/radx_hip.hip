@@ -24,9 +24,16 @@
 //     touches at most 2 destination tiles: at most 2*16*16 counters per workgroup, kept in LDS
 //     and flushed once with global atomic adds.
 //
+//   * Inputs of at most 8192 tiles run without scan kernels: a few extra workgroups at the front
+//     of every scatter launch scan that pass's table and publish the results, and every tile
+//     workgroup picks up its 16 output bases from them (see scatter_kernel, SCANLESS).  One launch
+//     per pass instead of three.
+//
 // All cross-wave LDS hand-offs are separated by __syncthreads().  Workgroups never wait on each
-// other inside a launch; the only inter-workgroup traffic is no-return atomic adds whose sums are
-// read by a later kernel on the same stream.
+// other without a bound inside a launch: the inter-workgroup traffic is no-return atomic adds
+// whose sums are read by a later kernel on the same stream, and, in the scan-free passes, words
+// published once by workgroups that depend on nobody, which a reader that does not find them
+// after a bounded number of looks replaces by its own computation.
 #include <hip/hip_runtime.h>
 
 #include <stdint.h>
@@ -526,7 +533,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     __shared__ uint32_t self_sum_s;  // SCANLESS: some group sum never showed up, sum the table here
 
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    // SCANLESS: team = tid / 16 of 16 lanes reads table rows team, team + 16, ...; lane col of a team reads column col
+    // SCANLESS: table rows are read by teams of 16 lanes (team = tid / 16), lane tcol of a team reading column tcol
     const uint32_t tcol = tid & 15u, team = tid >> 4;
     const uint32_t num_grps = (num_tiles + kGroupTiles - 1u) >> kLogGroupTiles;
     const uint32_t publishers = SCANLESS ? (num_grps + 1u + 7u) & ~7u : 0u;
