@@ -1463,7 +1463,7 @@ int empty_pass(radx_hip_sorter* s, hipStream_t stream) {
 
 extern "C" {
 
-int radx_hip_version(void) { return 300; }
+int radx_hip_version(void) { return 400; }
 
 const char* radx_hip_error_string(void) { return g_error; }
 
