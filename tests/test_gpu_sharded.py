@@ -301,3 +301,33 @@ def test_sharded_sorter_follows_key_order(device, kind, descending):
     everything = np.concatenate(inputs)
     expect = everything[np.argsort(ordered_image(everything, kind, descending), kind="stable")]
     assert np.array_equal(np.concatenate(whole), expect)
+
+
+def test_run_starts_stay_on_the_device_and_table_views(device):
+    """radx_hip_digit_starts_async copies the 17 run starts in stream order into device memory (what
+    the multi-GPU hosts gather without a host wait), equal to the synchronising getter; and
+    radx_hip_device_tables names the tables' device addresses: one complete offsets table for
+    scan-free passes, offsets + group bases where the scan kernels ran."""
+    import torch
+    import radx_amd
+    n = 100 * 4096 + 17
+    s = radx_amd.Sorter(n, 4, 0)
+    src = to_dev(make_keys("hash", n, 4, seed=5), device)
+    dst = torch.empty_like(src)
+    out = torch.full((18,), -1, dtype=torch.int32, device=device)
+    s.msd_split(src, dst, 3)
+    s.digit_starts_into(out)
+    torch.cuda.synchronize()
+    assert np.array_equal(out[:17].cpu().numpy().view(np.uint32), s.digit_starts())
+    assert int(out[17].item()) == -1                      # exactly 17 words are written
+    counts, offsets, bases, per_group = s.device_tables(n)
+    assert counts and offsets and bases is None and per_group == 256   # 101 tiles: scan-free, complete table
+    s.tune(True, scan_kernels=True)
+    s.msd_split(src, dst, 3)
+    counts, offsets, bases, _ = s.device_tables(n)
+    assert counts and offsets and bases
+    with pytest.raises(radx_amd.RadxError):
+        s.device_tables(n - 1)                            # no tables for another element count
+    with pytest.raises(ValueError):
+        s.digit_starts_into(torch.empty(8, dtype=torch.int32, device=device))
+    s.close()
