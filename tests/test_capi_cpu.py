@@ -80,3 +80,13 @@ def test_reference_call_sequence_compiles_against_these_headers():
     assert made.returncode == 0, made.stdout + made.stderr
     assert "warning" not in made.stderr, made.stderr
     assert os.access(os.path.join(ROOT, "harness", "reference_sequence"), os.X_OK)
+
+
+def test_header_is_plain_c():
+    """The boundary is a C ABI: include/radx_hip.h compiles as C99 (and as C++) on its own, with
+    nothing but <stddef.h> / <stdint.h> behind it."""
+    header = os.path.join(ROOT, "include", "radx_hip.h")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", header],
+                ["g++", "-std=c++17", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-x", "c++", header]):
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=60)
+        assert out.returncode == 0, out.stderr
