@@ -74,6 +74,12 @@ int radx_hip_destroy(radx_hip_sorter* s);
  * Enqueue a full ascending, unsigned, stable sort of n elements on `stream`
  * (a hipStream_t passed as void*; NULL is the default stream).
  * vals / vals_swap must be NULL for a keys-only sorter and non-NULL otherwise.
+ * An input of at most one tile (radx_hip_geometry: 4096 4-byte or 2048 8-byte keys) is sorted by
+ * one launch of one workgroup that keeps the keys in LDS through all passes — same digits, same
+ * result, same 17 run starts (radx_hip_digit_starts), but no histogram / prefix-scan tables are
+ * made: radx_hip_copy_tables and radx_hip_device_tables then return hipErrorInvalidValue.  The
+ * same holds for radx_hip_sort_bits, radx_hip_sort_bits_into and radx_hip_sort_noalloc;
+ * radx_hip_tune bit 1 (or a cleared bit 0) keeps the pass structure, tables included, at every size.
  */
 int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals,
                   void* vals_swap, uint64_t n, void* stream);
@@ -167,14 +173,15 @@ int radx_hip_pass_fused(radx_hip_sorter* s, const void* keys_in, void* keys_out,
 int radx_hip_set_key_order(radx_hip_sorter* s, int key_kind, int descending);
 
 /*
- * Tuning knobs, as a bit set (default 1).  The sorted result and the tables radx_hip_copy_tables
- * returns do not depend on any of them.
+ * Tuning knobs, as a bit set (default 1).  The sorted result, the run starts and the tables
+ * radx_hip_copy_tables returns do not depend on any of them (with the default, a whole sort of at
+ * most one tile leaves no tables at all, see radx_hip_sort).
  *   bit 0  fuse the histogram: every scatter pass of a sort also produces the next pass's
  *          histogram; clear, the histogram kernel runs every pass (three launches per pass, the
  *          reference's counting -> partition -> scattering, radx_implement.inl:427-444).
  *   bit 1  always run the scan kernels.  Clear (default), inputs of at most 8192 tiles sorted with
  *          bit 0 set run scan-free: the partition step is done by a few extra workgroups inside
- *          the scatter launch, one launch per pass.
+ *          the scatter launch, one launch per pass; and a sort of at most one tile is one launch.
  *   bit 2 / bit 3 (tests; at most one of them)  scan-free passes publish nothing / no group sums,
  *          which makes every tile workgroup / the scanning workgroup sum the table itself — the
  *          bounded-wait fallbacks that normal runs never take.

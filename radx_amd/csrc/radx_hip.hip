@@ -28,6 +28,9 @@
 //     of every scatter launch scan that pass's table and publish the results, and every tile
 //     workgroup picks up its 16 output bases from them (see scatter_kernel, SCANLESS).  One launch
 //     per pass instead of three.
+//   * Inputs of at most one tile are sorted by one launch of one workgroup: the keys stay in LDS
+//     through all passes (sort_tile_kernel).  Same digits, same stable rank, one launch instead
+//     of nine.
 //
 // All cross-wave LDS hand-offs are separated by __syncthreads().  Workgroups never wait on each
 // other without a bound inside a launch: the inter-workgroup traffic is no-return atomic adds
@@ -1041,6 +1044,112 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
 }
 
 // ---------------------------------------------------------------------------------------------
+// Inputs of at most one tile (4096 4-byte / 2048 8-byte keys): the whole pass loop of
+// include/radx/radx_implement.inl:427-444 in ONE launch of one workgroup.  Nothing has to travel
+// between workgroups, so no table leaves the CU: per pass the same thread-private packed
+// counters, the same block-wide scan and the same rank-ordered LDS array as in scatter_kernel
+// (its steps 2-4), after which thread t takes back the keys of ranks [t*KPT, (t+1)*KPT) and the
+// next pass ranks those.  Keys past n are all-ones in the ordered image: they sort behind every
+// real key (ties keep address order, and they come last) and are not stored.
+// ---------------------------------------------------------------------------------------------
+template <typename K, bool HAS_V>
+__global__ __launch_bounds__(kBlock) void sort_tile_kernel(const K* __restrict__ kin, K* __restrict__ kout,
+                                                            const uint32_t* __restrict__ vin, uint32_t* __restrict__ vout,
+                                                            uint32_t n, int begin_bit, int end_bit, int order,
+                                                            int padding_pass, uint32_t* __restrict__ digit_starts) {
+    constexpr int KPT = KeyTraits<K>::kpt;
+    constexpr uint32_t TILE = kBlock * KPT;
+    __shared__ K skeys[TILE];
+    __shared__ uint32_t svals[HAS_V ? TILE : 1];
+    __shared__ __attribute__((aligned(16))) uint32_t ctr[kCtrRows * kBlock];
+    __shared__ uint32_t wave_tot[kBlock / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+
+    K key[KPT];
+    uint32_t val[HAS_V ? KPT : 1];
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t e = tid * KPT + i;
+        key[i] = e < n ? key_to_ordered<K>(kin[e], order) : static_cast<K>(~static_cast<K>(0));
+        if (HAS_V) val[i] = e < n ? vin[e] : 0u;
+    }
+    for (int bit = begin_bit; bit < end_bit; bit += kDigitBits) {
+        const int width = end_bit - bit < kDigitBits ? end_bit - bit : kDigitBits;
+        const uint32_t mask = (1u << width) - 1u;
+#pragma unroll
+        for (int r = 0; r < kCtrRows; ++r) ctr[r * kBlock + tid] = 0u;
+        __syncthreads();  // also: every thread has taken the previous pass's keys back out of skeys
+        uint32_t rank[KPT];
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t d = digit_of<K>(key[i], bit, mask);
+            const uint32_t sh = (d >> 3) << 4;
+            const uint32_t old = __hip_atomic_fetch_add(&ctr[(d & 7u) * kBlock + tid], 1u << sh, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_WORKGROUP);
+            rank[i] = (old >> sh) & 0xffffu;
+        }
+        __syncthreads();
+        {   // block-wide exclusive scan, thread t owning words 8t..8t+7 of the row-major counter array
+            const uint4 a = *reinterpret_cast<const uint4*>(&ctr[tid * 8u]);
+            const uint4 b = *reinterpret_cast<const uint4*>(&ctr[tid * 8u + 4u]);
+            const uint32_t c[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            uint32_t total = 0;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) total += c[i];
+            const uint32_t incl = wave_inclusive_scan(total);
+            if (lane == 63u) wave_tot[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0, all = 0;
+#pragma unroll
+            for (int w = 0; w < kBlock / 64; ++w) {
+                const uint32_t t = wave_tot[w];
+                if (static_cast<uint32_t>(w) < wave) before += t;
+                all += t;
+            }
+            // digits 8..15 (high halves) sort after all of digits 0..7 (low halves)
+            uint32_t run = incl - total + before + ((all & 0xffffu) << 16);
+            uint32_t o[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { o[i] = run; run += c[i]; }
+            *reinterpret_cast<uint4*>(&ctr[tid * 8u]) = make_uint4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<uint4*>(&ctr[tid * 8u + 4u]) = make_uint4(o[4], o[5], o[6], o[7]);
+        }
+        __syncthreads();
+        // the 17 run starts of the last pass, as the multi-launch passes leave them: thread 0's
+        // counter of digit d is where d's run begins (the pads all follow the last real key)
+        if (bit + kDigitBits >= end_bit && !padding_pass && tid <= kRadices) {
+            uint32_t start = n;
+            if (tid < kRadices) start = min(start, (ctr[(tid & 7u) * kBlock] >> ((tid >> 3) << 4)) & 0xffffu);
+            digit_starts[tid] = start;
+        }
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            const uint32_t d = digit_of<K>(key[i], bit, mask);
+            const uint32_t sh = (d >> 3) << 4;
+            rank[i] += (ctr[(d & 7u) * kBlock + tid] >> sh) & 0xffffu;  // below TILE: the counters add up to TILE
+            skeys[rank_slot<sizeof(K)>(rank[i])] = key[i];
+            if (HAS_V) svals[rank_slot<4>(rank[i])] = val[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < KPT; ++i) {
+            key[i] = skeys[rank_slot<sizeof(K)>(tid * KPT + i)];
+            if (HAS_V) val[i] = svals[rank_slot<4>(tid * KPT + i)];
+        }
+    }
+    // a padding pass (zero-width digit, a stable copy) moves nothing: only its run starts remain
+    if (padding_pass && tid <= kRadices) digit_starts[tid] = tid == 0 ? 0u : n;
+#pragma unroll
+    for (int i = 0; i < KPT; ++i) {
+        const uint32_t e = tid * KPT + i;
+        if (e < n) {
+            kout[e] = ordered_to_key<K>(key[i], order);
+            if (HAS_V) vout[e] = val[i];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // index path: the reference's indiction / permutation kernels (shaders-sdk/radix/indiction.comp:18-29,
 // permutation.comp:18-29; built by Radix::initialize, never dispatched by Radix::command).  They
 // exist so that wide payloads need not ride through every pass: sort (key, index) pairs, then
@@ -1558,6 +1667,44 @@ namespace {
 // to keys_out / vals_out instead of its ping-pong partner.
 int sort_bits_impl(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals, void* vals_swap, uint64_t n,
                    int begin_bit, int end_bit, void* keys_out, void* vals_out, hipStream_t stream) {
+    // At most one tile: all passes in one launch of one workgroup, the result straight to its
+    // place (keys_swap is not needed).  Not in the modes that ask for the reference's pass
+    // structure (histogram kernel every pass, or scan kernels).
+    if (geometry_for(n, s->key_bytes).num_tiles == 1 && s->fuse && !s->scan_kernels) {
+        {
+            LaunchTimer t(s, 2, stream);
+            const uint32_t n32 = static_cast<uint32_t>(n);
+            // what the pass loop below would add: a zero-width pass to make the count even, or
+            // the one pass a sort over no bits into keys_out still runs
+            const int real_passes = (end_bit - begin_bit + kDigitBits - 1) / kDigitBits;
+            const int padding_pass = keys_out ? real_passes == 0 : (real_passes & 1);
+            const uint32_t* vin = static_cast<const uint32_t*>(vals);
+            uint32_t* vout = static_cast<uint32_t*>(keys_out ? vals_out : vals);
+            if (s->key_bytes == 4) {
+                const uint32_t* kin = static_cast<const uint32_t*>(keys);
+                uint32_t* kout = static_cast<uint32_t*>(keys_out ? keys_out : keys);
+                if (s->value_bytes)
+                    hipLaunchKernelGGL((sort_tile_kernel<uint32_t, true>), dim3(1), dim3(kBlock), 0, stream, kin, kout, vin, vout,
+                                       n32, begin_bit, end_bit, s->key_order, padding_pass, s->digit_starts);
+                else
+                    hipLaunchKernelGGL((sort_tile_kernel<uint32_t, false>), dim3(1), dim3(kBlock), 0, stream, kin, kout, vin, vout,
+                                       n32, begin_bit, end_bit, s->key_order, padding_pass, s->digit_starts);
+            } else {
+                const uint64_t* kin = static_cast<const uint64_t*>(keys);
+                uint64_t* kout = static_cast<uint64_t*>(keys_out ? keys_out : keys);
+                if (s->value_bytes)
+                    hipLaunchKernelGGL((sort_tile_kernel<uint64_t, true>), dim3(1), dim3(kBlock), 0, stream, kin, kout, vin, vout,
+                                       n32, begin_bit, end_bit, s->key_order, padding_pass, s->digit_starts);
+                else
+                    hipLaunchKernelGGL((sort_tile_kernel<uint64_t, false>), dim3(1), dim3(kBlock), 0, stream, kin, kout, vin, vout,
+                                       n32, begin_bit, end_bit, s->key_order, padding_pass, s->digit_starts);
+            }
+        }
+        RADX_TRY(hipGetLastError());
+        s->tables_n = 0;  // no tables were made
+        s->chained = false;
+        return 0;
+    }
     int passes = (end_bit - begin_bit + kDigitBits - 1) / kDigitBits;
     if (keys_out) passes = passes ? passes : 1;
     else passes += passes & 1;  // even, so the result ends in `keys` (scattering.comp:40,143)

@@ -542,3 +542,78 @@ def test_profiling_for_a_long_time_without_reading(device):
     assert t["scatter"][0] > 0
     assert np.array_equal(to_host(k), np.sort(keys))
     s.close()
+
+
+@pytest.mark.parametrize("key_bytes", [4, 8])
+@pytest.mark.parametrize("with_vals", [False, True])
+def test_single_tile_inputs(device, key_bytes, with_vals):
+    """Inputs of at most one tile are sorted by one launch of one workgroup (all passes in LDS):
+    every size class up to the tile, ties with payloads (stability), bit sub-ranges with odd pass
+    counts, key orders, the packed destination of sort_bits_into at an odd element offset — and
+    the same inputs once more through the multi-launch passes, which must agree bit for bit."""
+    import torch
+    import radx_amd
+    tile = 4096 if key_bytes == 4 else 2048
+    bits = key_bytes * 8
+    s = radx_amd.Sorter(tile, key_bytes, 4 if with_vals else 0)
+    for n in (1, 2, 3, 63, 64, 255, 257, 1000, tile - 1, tile):
+        for dist, (lo, hi), (kind, desc) in (("uniform", (0, bits), ("unsigned", False)),
+                                             ("few_distinct", (0, bits), ("signed", True)),
+                                             ("skewed", (4, 17), ("unsigned", False)),
+                                             ("all_equal", (bits - 3, bits), ("unsigned", False)),
+                                             ("hash", (0, bits), ("float", False)),
+                                             ("uniform", (8, 8), ("unsigned", False))):
+            keys = make_keys(dist, n, key_bytes, seed=n + lo)
+            vals = np.arange(n, dtype=np.uint32)[::-1].copy()
+            whole = (lo, hi) == (0, bits)
+            if whole:
+                field = ordered_image(keys, kind, desc)
+            else:
+                field = (keys >> keys.dtype.type(lo)) & keys.dtype.type((1 << (hi - lo)) - 1)
+            order = np.argsort(field, kind="stable")
+            results = []
+            for scan_kernels in (False, True):   # one launch of one workgroup / the pass structure
+                s.tune(True, scan_kernels=scan_kernels)
+                s.set_key_order(kind if whole else "unsigned", desc if whole else False)
+                k = to_dev(keys, device) if n >= 4 else to_dev(np.concatenate([keys, np.zeros(4, keys.dtype)]), device)
+                swap = torch.empty_like(k)
+                v = vswap = None
+                if with_vals:
+                    v = to_dev(vals if n >= 4 else np.concatenate([vals, np.zeros(4, np.uint32)]), device)
+                    vswap = torch.empty_like(v)
+                if whole:
+                    s.sort(k, swap, v, vswap, n=n)
+                else:
+                    s.sort_bits(k, swap, lo, hi, v, vswap, n=n)
+                torch.cuda.synchronize()
+                got = (to_host(k, key_bytes)[:n], to_host(v)[:n] if with_vals else None)
+                assert np.array_equal(got[0], keys[order]), (n, dist, lo, hi, kind, desc, scan_kernels)
+                if with_vals:
+                    assert np.array_equal(got[1], vals[order]), (n, dist, lo, hi, kind, desc, scan_kernels)
+                results.append(got + (np.asarray(s.digit_starts()),))
+            assert np.array_equal(results[0][0], results[1][0])
+            if hi > lo:   # the 17 run starts of the last pass are the same either way
+                assert np.array_equal(results[0][2], results[1][2]), (n, dist, lo, hi, results[0][2], results[1][2])
+    # sort_bits_into: exact pass count, result stored at an odd element offset of a third buffer
+    s.tune(True)
+    s.set_key_order("unsigned", False)
+    n = tile - 5
+    keys = make_keys("few_distinct", n, key_bytes, seed=77)
+    vals = np.arange(n, dtype=np.uint32)
+    k = to_dev(np.concatenate([keys, np.zeros(5, keys.dtype)]), device)
+    swap = torch.empty_like(k)
+    out = torch.zeros(n + 8, dtype=k.dtype, device=device)
+    v = to_dev(np.concatenate([vals, np.zeros(5, np.uint32)]), device) if with_vals else None
+    vswap = torch.empty_like(v) if with_vals else None
+    vout = torch.zeros(n + 8, dtype=torch.int32, device=device) if with_vals else None
+    s.sort_bits_into(k, swap, out[3:], 0, bits - 4, v, vswap, vout[3:] if with_vals else None, n=n)
+    torch.cuda.synchronize()
+    field = keys & keys.dtype.type((1 << (bits - 4)) - 1)
+    order = np.argsort(field, kind="stable")
+    got = to_host(out, key_bytes)
+    assert np.array_equal(got[3:3 + n], keys[order]) and not got[:3].any() and not got[3 + n:].any()
+    if with_vals:
+        assert np.array_equal(to_host(vout)[3:3 + n], vals[order])
+    with pytest.raises(radx_amd.RadxError):   # one launch, keys never left the CU: no tables were made
+        s.tables(n)
+    s.close()
