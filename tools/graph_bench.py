@@ -1,52 +1,94 @@
-"""Development timing: a sort enqueued kernel by kernel vs the same sort replayed from a HIP graph,
-over a range of sizes.  python tools/graph_bench.py [log2n ...]"""
+"""Launch cost of small and mid-size sorts: the same (generate keys, sort) step enqueued call by
+call and replayed from a captured HIP graph.
+
+  python tools/graph_bench.py [--lo 10] [--hi 24] [--step 2] [--types u32,u64kv]
+
+Per size: K steps back to back without host synchronisation, bracketed by two events; the
+generate-only loop is timed the same way and subtracted, so the figure is the sort alone.  The
+library's calls only enqueue kernels on the given stream, so a sort is capturable as it is.
+"""
+import argparse
 import sys
-import time
 
 import torch
 
 sys.path.insert(0, __file__.rsplit("/", 2)[0])
 import radx_amd
 
-dev = torch.device("cuda:0")
-sizes = [int(a) for a in sys.argv[1:]] or [16, 20, 22, 24, 26, 28]
-for log2n in sizes:
-    n = 1 << log2n
-    src = torch.empty(n, dtype=torch.int32, device=dev)
-    radx_amd.generate_u32(src, seed=5)
-    k = torch.empty_like(src)
-    swap = torch.empty_like(src)
-    s = radx_amd.Sorter(n)
-    reps = 20
 
-    def one():
-        k.copy_(src)
-        s.sort(k, swap)
-
-    def copy_only():
-        k.copy_(src)
-
-    def timed(fn):
-        fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3
-
-    t_copy = timed(copy_only)
-    t_stream = timed(one) - t_copy
-    side = torch.cuda.Stream()
-    with torch.cuda.stream(side):
-        one()
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            one()
+def timed(fn, reps):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
     torch.cuda.synchronize()
-    t_graph = timed(g.replay) - t_copy
-    ok = radx_amd.check_sorted(k) == 0
-    print("2^%d: stream %.4f ms  graph %.4f ms  (%.2f / %.2f Gkeys/s) sorted=%s"
-          % (log2n, t_stream, t_graph, n / t_stream / 1e6, n / t_graph / 1e6, ok), flush=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def measure(log2n, kb, vb, reps):
+    n = 1 << log2n
+    dev = torch.device("cuda:0")
+    k = torch.empty(n, dtype=torch.int32 if kb == 4 else torch.int64, device=dev)
+    swap = torch.empty_like(k)
+    v = vswap = None
+    if vb:
+        v = torch.empty(n, dtype=torch.int32, device=dev)
+        vswap = torch.empty_like(v)
+    s = radx_amd.Sorter(n, kb, vb)
+
+    def gen():
+        if kb == 4:
+            radx_amd.generate_u32(k, seed=7)
+            if vb:
+                radx_amd.generate_u32(v, seed=9)
+        else:
+            radx_amd.generate_u64(k, v, seed=7)
+
+    def step():
+        gen()
+        s.sort(k, swap, v, vswap)
+
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    g_gen, g_step = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g_gen, stream=side):
+            gen()
+        with torch.cuda.graph(g_step, stream=side):
+            step()
+    torch.cuda.synchronize()
+    # warm the clocks
+    for _ in range(max(20, int(2e5 / max(n, 1)) // 100)):
+        g_step.replay()
+    eager = timed(step, reps) - timed(gen, reps)
+    graph = timed(g_step.replay, reps) - timed(g_gen.replay, reps)
+    g_step.replay()
+    bad = radx_amd.check_sorted(k, v)
     s.close()
+    return eager, graph, bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--lo", type=int, default=10)
+    ap.add_argument("--hi", type=int, default=24)
+    ap.add_argument("--step", type=int, default=2)
+    ap.add_argument("--types", type=str, default="u32,u64kv")
+    ap.add_argument("--reps", type=int, default=200)
+    a = ap.parse_args()
+    shapes = {"u32": (4, 0), "u32kv": (4, 4), "u64": (8, 0), "u64kv": (8, 4)}
+    print("type    log2n   call-by-call us   graph replay us   ratio | viol", flush=True)
+    for t in a.types.split(","):
+        kb, vb = shapes[t]
+        for l in range(a.lo, a.hi + 1, a.step):
+            eager, graph, bad = measure(l, kb, vb, a.reps)
+            print(f"{t:6s} {l:6d} {1e3 * eager:17.1f} {1e3 * graph:17.1f} {eager / graph:7.2f} | {bad}", flush=True)
+
+
+if __name__ == "__main__":
+    main()
