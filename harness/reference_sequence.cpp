@@ -133,10 +133,10 @@ public:
         return pass ? 0 : 1;
     }
 
-    // Above 8192 tiles the scan kernels leave the prefix table in two parts: the same check of
+    // Above 16384 tiles the scan kernels leave the prefix table in two parts: the same check of
     // partitions[g][r] through prefixScansBufferInfo + prefixGroupBasesBufferInfo.
     bool twoPartTables() {
-        const size_t n = size_t(8200) * 4096 + 5;   // 8201 tiles
+        const size_t n = size_t(16392) * 4096 + 5;   // 16393 tiles
         auto sorter = std::make_shared<OpenSort>();
         sorter->initialize(device, program, n);
         auto buffer = std::make_shared<radx::VmaAllocatedBuffer>(device, 2 * (n + 3) * sizeof(uint32_t), 0, radx::MEMORY_USAGE_GPU_ONLY);
@@ -151,7 +151,7 @@ public:
         radx::check_abi(radx_hip_check_sorted(keys.deviceData(), nullptr, n, 4, &bad, nullptr));
         radx::InternalInterface& internal = sorter->internal();
         const size_t words = internal.histogramBufferInfo.range / sizeof(uint32_t), tiles = words / 16;
-        if (bad || tiles != 8201 || !internal.prefixGroupBasesBufferInfo.buffer || !internal.prefixTilesPerGroup) return false;
+        if (bad || tiles != 16393 || !internal.prefixGroupBasesBufferInfo.buffer || !internal.prefixTilesPerGroup) return false;
         const size_t groups = internal.prefixGroupBasesBufferInfo.range / (16 * sizeof(uint32_t));
         const size_t tilesPerGroup = internal.prefixTilesPerGroup;
         std::vector<uint32_t> counts(words), prefix(words), bases(groups * 16);

@@ -39,7 +39,7 @@ namespace radx {
         // partition.comp:26): device memory holding counts[tile][16] and partitions[tile][16] of
         // the LAST pass of the last command(), refreshed by Radix::command (the engine rotates
         // its tables, so the addresses change from sort to sort).  prefixScansBufferInfo is the
-        // complete table when prefixGroupBasesBufferInfo.buffer is null (inputs of up to 8192
+        // complete table when prefixGroupBasesBufferInfo.buffer is null (inputs of up to 16384
         // tiles); for larger inputs the scan kernels leave it in two parts, see
         // radx_hip_device_tables.  The key staging views are the reference's 256-byte stubs
         // (radx_implement.inl:463-471): nothing reads them, here as there.

@@ -89,7 +89,7 @@ int radx_hip_sort(radx_hip_sorter* s, void* keys, void* keys_swap, void* vals,
  * the reference (whose scratch is always a buffer allocated by Radix::createInternalMemory); it is
  * for callers that cannot call hipMalloc — code under HIP graph capture, tight serving loops,
  * harnesses that forbid allocation.  The histogram / prefix-scan tables live in a fixed device
- * array inside the library's code object (about 8 MiB, resident on every GPU the library is loaded
+ * array inside the library's code object (about 10 MiB, resident on every GPU the library is loaded
  * on until the process ends), so n is limited to RADX_HIP_NOALLOC_MAX_N elements; larger n fails
  * with hipErrorInvalidValue and a message.  Unsigned ascending order; key_bytes 4 or 8,
  * value_bytes 0 or 4, buffers as for radx_hip_sort.  The call makes no hipMalloc / hipFree and
@@ -179,7 +179,7 @@ int radx_hip_set_key_order(radx_hip_sorter* s, int key_kind, int descending);
  *   bit 0  fuse the histogram: every scatter pass of a sort also produces the next pass's
  *          histogram; clear, the histogram kernel runs every pass (three launches per pass, the
  *          reference's counting -> partition -> scattering, radx_implement.inl:427-444).
- *   bit 1  always run the scan kernels.  Clear (default), inputs of at most 8192 tiles sorted with
+ *   bit 1  always run the scan kernels.  Clear (default), inputs of at most 16384 tiles sorted with
  *          bit 0 set run scan-free: the partition step is done by a few extra workgroups inside
  *          the scatter launch, one launch per pass; and a sort of at most one tile is one launch.
  *   bit 2 / bit 3 (tests; at most one of them)  scan-free passes publish nothing / no group sums,

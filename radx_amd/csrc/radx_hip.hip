@@ -24,7 +24,7 @@
 //     touches at most 2 destination tiles: at most 2*16*16 counters per workgroup, kept in LDS
 //     and flushed once with global atomic adds.
 //
-//   * Inputs of at most 8192 tiles run without scan kernels: a few extra workgroups at the front
+//   * Inputs of at most 16384 tiles run without scan kernels: a few extra workgroups at the front
 //     of every scatter launch scan that pass's table and publish the results, and every tile
 //     workgroup picks up its 16 output bases from them (see scatter_kernel, SCANLESS).  One launch
 //     per pass instead of three.
@@ -60,17 +60,21 @@ constexpr int kTileDwords = kBlock * kThreadDwords;  // 16 KiB of keys per tile
 constexpr int kCtrRows = kRadices / 2;  // packed counters: digit d lives in row d&7, half d>>3
 constexpr int kScanBlocks = 256;        // table rows (workgroups) scanned by one scan workgroup
 // Inputs of at most kScanlessMaxTiles tiles run without scan kernels: a few extra workgroups of
-// the scatter launch publish the column sums of every group of kGroupTiles table rows, and every
+// the scatter launch publish the column sums of every group of 64 table rows (128 rows above
+// kSmallGroupMaxTiles tiles: never more than kMaxGroups groups), and every
 // scatter workgroup derives its own 16 output bases from those sums and the rows of its own group.
-constexpr int kLogGroupTiles = 6;
-constexpr uint32_t kGroupTiles = 1u << kLogGroupTiles;
-constexpr uint32_t kScanlessMaxTiles = 8192;
-constexpr int kGroupIters = kScanlessMaxTiles / kGroupTiles / 16;  // group rows per 16-lane team: 8
-constexpr int kRowIters = kGroupTiles / 16;                       // own-group rows per 16-lane team: 4
-constexpr uint32_t kGroupValid = 0x80000000u;  // a published group sum (below 2^25: 8192 tiles of 4096 keys) carries this bit
+constexpr uint32_t kScanlessMaxTiles = 16384;
+constexpr uint32_t kSmallGroupMaxTiles = 8192;
+constexpr uint32_t kMaxGroups = 128;
+__host__ __device__ constexpr int log_group_tiles(uint32_t num_tiles) { return num_tiles <= kSmallGroupMaxTiles ? 6 : 7; }
+__host__ __device__ constexpr uint32_t group_count(uint32_t num_tiles) {
+    return (num_tiles + (1u << log_group_tiles(num_tiles)) - 1u) >> log_group_tiles(num_tiles);
+}
+constexpr int kGroupIters = kMaxGroups / 16;                      // group rows per 16-lane team: 8
+constexpr int kMaxRowIters = (kScanlessMaxTiles / kMaxGroups) / 16;  // own-group rows per 16-lane team: 4 or 8
+constexpr uint32_t kGroupValid = 0x80000000u;  // a published word (at most 2^26: 16384 tiles of 4096 keys) carries this bit
 constexpr int kMaxPolls = 64;                  // looks at an unpublished word before a workgroup sums the table itself
 // One buffer of group words: kMaxGroups rows of 16 column sums, then kMaxGroups rows of 16 output bases.
-constexpr uint32_t kMaxGroups = kScanlessMaxTiles / kGroupTiles;
 constexpr uint32_t kGroupBaseWords = kMaxGroups * 16;  // where the bases start
 // Up to this many groups every tile workgroup adds up the group sums itself (2 table rows per
 // team of 16 lanes) instead of waiting for the scanning workgroup's bases: one step less in the
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(kBlock) void hist_kernel(const K* __restrict__ keys
     }
     if (zero_groups_a) {
         const uint32_t w = blockIdx.x * kBlock + tid;
-        if (w < ((num_tiles + kGroupTiles - 1u) >> kLogGroupTiles) * kRadices) {
+        if (w < group_count(num_tiles) * kRadices) {
             zero_groups_a[w] = 0u; zero_groups_a[kGroupBaseWords + w] = 0u;
             zero_groups_b[w] = 0u; zero_groups_b[kGroupBaseWords + w] = 0u;
         }
@@ -475,8 +479,8 @@ struct ScanFreeTables {
 
 // SCANLESS: no scan kernel runs for this pass; the scan is done by a few extra workgroups at the
 // front of the launch (their number rounded up to 8, which keeps the XCD of every tile workgroup).
-//   * Extra workgroup b < ceil(num_tiles / 64) scans the 16 columns of table rows [64 b, 64 b + 64)
-//     of `counts`: it publishes, for every one of its tiles, the 16 sums of the group's rows in
+//   * Extra workgroup b < ceil(num_tiles / G) scans the 16 columns of table rows [G b, G b + G)
+//     of `counts` (G = 64 rows, 128 above 8192 tiles): it publishes, for every one of its tiles, the 16 sums of the group's rows in
 //     front of that tile, and the 16 sums over the whole group.
 //   * The next extra workgroup waits for those sums, scans them in (digit, group) order and
 //     publishes, per group, the 16 output bases of the group's first tile (and the 17 run starts).
@@ -538,20 +542,23 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     // SCANLESS: table rows are read by teams of 16 lanes (team = tid / 16), lane tcol of a team reading column tcol
     const uint32_t tcol = tid & 15u, team = tid >> 4;
-    const uint32_t num_grps = (num_tiles + kGroupTiles - 1u) >> kLogGroupTiles;
+    const int log_group = log_group_tiles(num_tiles);
+    const uint32_t num_grps = group_count(num_tiles);
     const uint32_t publishers = SCANLESS ? (num_grps + 1u + 7u) & ~7u : 0u;
     if (SCANLESS && blockIdx.x < publishers) {
         const uint32_t b = blockIdx.x;
         if (b > num_grps || sf.publish == 0) return;
         if (b == num_grps && num_grps <= kOneLevelGroups) return;  // nobody reads the bases
         if (b < num_grps) {
-            // One group of table rows.  Team t owns rows 4t .. 4t+3 of the group, lane c column c:
-            // exclusive scan down every column, then the column sums.
-            uint32_t c[kRowIters], mine = 0;
+            // One group of table rows.  Team t owns rows 4t .. 4t+3 (8t .. 8t+7 in groups of 128) of
+            // the group, lane c column c: exclusive scan down every column, then the column sums.
+            const uint32_t team_rows = 1u << (log_group - 4);
+            const uint32_t first_row = (b << log_group) + team * team_rows;
+            uint32_t c[kMaxRowIters], mine = 0;
 #pragma unroll
-            for (int i = 0; i < kRowIters; ++i) {
-                const uint32_t r = b * kGroupTiles + team * kRowIters + i;
-                c[i] = r < num_tiles ? counts[static_cast<size_t>(r) * kRadices + tcol] : 0u;
+            for (int i = 0; i < kMaxRowIters; ++i) {
+                const uint32_t r = first_row + i;
+                c[i] = static_cast<uint32_t>(i) < team_rows && r < num_tiles ? counts[static_cast<size_t>(r) * kRadices + tcol] : 0u;
                 mine += c[i];
             }
             uint32_t incl = mine;  // over the teams of this wave
@@ -569,9 +576,9 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
                 all += t;
             }
 #pragma unroll
-            for (int i = 0; i < kRowIters; ++i) {
-                const uint32_t r = b * kGroupTiles + team * kRowIters + i;
-                if (r < num_tiles)
+            for (int i = 0; i < kMaxRowIters; ++i) {
+                const uint32_t r = first_row + i;
+                if (static_cast<uint32_t>(i) < team_rows && r < num_tiles)
                     __hip_atomic_store(&sf.prefix_words[static_cast<size_t>(r) * kRadices + tcol], run | kGroupValid,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 run += c[i];
@@ -604,7 +611,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
                 const uint32_t r = team * kGroupIters + i;
                 uint32_t sum = 0;
 #pragma unroll 1
-                for (uint32_t t = r * kGroupTiles; t < min((r + 1u) * kGroupTiles, num_tiles); ++t)
+                for (uint32_t t = r << log_group; t < min((r + 1u) << log_group, num_tiles); ++t)
                     sum += counts[static_cast<size_t>(t) * kRadices + tcol];
                 w[i] = sum;
             }
@@ -653,7 +660,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
 
     // Global output base of every digit for this tile; issued first, consumed after the scan.
     uint32_t run_base = 0, run_len = 0;
-    const uint32_t my_grp = g >> kLogGroupTiles;
+    const uint32_t my_grp = g >> log_group;
     uint32_t base_word = kGroupValid, prefix_word = kGroupValid, grp_word[SCANLESS ? kOneLevelIters : 1];
     const bool one_level = num_grps <= kOneLevelGroups;
     // Lanes 0..15 of wave 0: the tile's sums over its own group's rows in front of it.  One level:
@@ -1481,7 +1488,7 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
         const ScanFreeTables sf{s->group_tot[s->cur], s->prefix_words[s->cur], s->counts[after], s->group_tot[after],
                                 s->prefix_words[after], s->digit_starts, s->publish};
         // the workgroups that publish the group sums come first, rounded up to the number of XCDs
-        const uint32_t grid = g.num_tiles + (((g.num_tiles + kGroupTiles - 1u) / kGroupTiles + 1u + 7u) & ~7u);
+        const uint32_t grid = g.num_tiles + ((group_count(g.num_tiles) + 1u + 7u) & ~7u);
         LaunchTimer t(s, 2, stream);
         if (a.fuse_next)
             hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true, true>), dim3(grid), dim3(kBlock), hold_back, stream,
@@ -1822,7 +1829,7 @@ namespace {
 constexpr uint64_t kNoAllocMaxN = RADX_HIP_NOALLOC_MAX_N;
 constexpr size_t kNoAllocScratchBytes = layout_for(kNoAllocMaxN, 8).total;  // 8-byte keys have the smaller tile: more rows
 static_assert(layout_for(kNoAllocMaxN, 4).total <= kNoAllocScratchBytes, "the 4-byte-key layout must fit as well");
-static_assert(kNoAllocScratchBytes <= (9u << 20), "keep the resident array modest");
+static_assert(kNoAllocScratchBytes <= (11u << 20), "keep the resident array modest");
 constexpr int kMaxDevices = 64;
 }  // namespace
 

@@ -75,7 +75,7 @@ def check_geometry(s, n, cfg):
 
 
 # The three ways a pass gets its tables: histogram kernel + scan kernels every pass; histogram
-# accumulated by the previous scatter + scan kernels; and scan-free (inputs of at most 8192 tiles
+# accumulated by the previous scatter + scan kernels; and scan-free (inputs of at most 16384 tiles
 # with the fused histogram: no scan kernel, every scatter workgroup derives its own bases).
 # "fused_self_sum" / "fused_scanner_self_sum" are the scan-free mode with its publishing workgroups
 # switched off (all of them / only those of the group sums): the tile workgroups, or the scanning
@@ -156,29 +156,37 @@ def test_u64_kv_every_pass_matches_oracle(device, n, mode):
     s.close()
 
 
-def test_u64_passes_above_the_scan_free_limit(device):
-    """8193 tiles: one more than the scan-free mode takes, so the default (fused) mode runs the
-    scan kernels with 33 scan groups; the last scan-free size, 8192 tiles = 128 row groups, next to
-    it.  Tables and output of the first three passes against the oracle."""
+@pytest.mark.parametrize("tiles,mode", [(8192, "fused"), (8193, "fused"), (8193, "fused_self_sum"),
+                                        (8200, "fused_scanner_self_sum"), (16384, "fused"), (16385, "fused")])
+def test_u64_passes_around_the_scan_free_limits(device, tiles, mode):
+    """8192 tiles: the last size with groups of 64 table rows (128 groups).  8193: the first with
+    groups of 128 rows (65 groups, the last one of a single row), also with nothing published
+    (every tile workgroup sums the table itself) and with no group sums published (the scanning
+    workgroup sums them).  16384: the last scan-free size (128 groups of 128).  16385: one more
+    than the scan-free mode takes, so the default (fused) mode runs the scan kernels with 65 scan
+    groups.  Tables, run starts and output of the first passes against the oracle."""
     import torch
     import radx_amd
-    for tiles in (8192, 8193):
-        n = (tiles - 1) * 2048 + 77
-        keys = make_keys("hash", n, 8, seed=tiles)
-        cfg = oracle.engine_config(n, 8)
-        s = radx_amd.Sorter(n, 8, 0)
-        assert s.geometry(n)[1] == tiles
-        cur = to_dev(keys, device)
-        nxt = torch.empty_like(cur)
-        host = keys
-        for p in range(3):
-            s.run_pass_fused(cur, nxt, 4 * p, 4, 4 * (p + 1), 4, use_fused_counts=p > 0)
-            counts, offsets = s.tables(n)
-            c, part, out = oracle.one_pass(cfg, host, p)
-            assert np.array_equal(counts, c) and np.array_equal(offsets, part), "tables, pass %d" % p
-            assert np.array_equal(to_host(nxt, 8), out), "scattered keys, pass %d" % p
-            cur, nxt, host = nxt, cur, out
-        s.close()
+    n = (tiles - 1) * 2048 + 77
+    keys = make_keys("hash", n, 8, seed=tiles)
+    cfg = oracle.engine_config(n, 8)
+    s = radx_amd.Sorter(n, 8, 0)
+    set_mode(s, mode)
+    assert s.geometry(n)[1] == tiles
+    cur = to_dev(keys, device)
+    nxt = torch.empty_like(cur)
+    host = keys
+    for p in range(3 if tiles <= 8200 else 2):
+        s.run_pass_fused(cur, nxt, 4 * p, 4, 4 * (p + 1), 4, use_fused_counts=p > 0)
+        counts, offsets = s.tables(n)
+        assert (s.device_tables(n)[2] is None) == (tiles <= 16384)   # complete table <=> scan-free
+        c, part, out = oracle.one_pass(cfg, host, p)
+        assert np.array_equal(counts, c) and np.array_equal(offsets, part), "tables, pass %d" % p
+        assert np.array_equal(to_host(nxt, 8), out), "scattered keys, pass %d" % p
+        starts = s.digit_starts()
+        assert starts[16] == n and np.array_equal(starts[:16], part[0])
+        cur, nxt, host = nxt, cur, out
+    s.close()
 
 
 @pytest.mark.parametrize("scan_kernels", [False, True])

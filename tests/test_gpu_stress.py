@@ -67,11 +67,13 @@ def test_random_sorts(device, seed):
 
 @pytest.mark.parametrize("key_bytes,with_vals,tiles,dist", [
     (4, False, 2049, "skewed"), (4, True, 3000, "heavy"), (8, True, 2600, "few_distinct"),
-    (8, False, 5000, "sorted"), (4, False, 8192, "all_equal"), (8, True, 8192, "heavy"), (4, True, 4097, "top_digit_only")])
+    (8, False, 5000, "sorted"), (4, False, 8192, "all_equal"), (8, True, 8192, "heavy"), (4, True, 4097, "top_digit_only"),
+    (4, False, 8193, "skewed"), (4, True, 12345, "heavy"), (8, True, 16384, "few_distinct"), (4, False, 16384, "all_equal"),
+    (8, False, 9999, "top_digit_only")])
 def test_scan_free_sizes_with_many_row_groups(device, key_bytes, with_vals, tiles, dist):
     """More than 32 groups of 64 table rows (above 2048 tiles): the scan-free passes then take
-    their output bases from the scanning workgroup.  Ragged sizes up to the last scan-free size
-    (8192 tiles), skewed and degenerate keys whose digit runs span many tiles and row groups,
+    their output bases from the scanning workgroup; above 8192 tiles the groups have 128 rows.
+    Ragged sizes up to the last scan-free size (16384 tiles), skewed and degenerate keys whose digit runs span many tiles and row groups,
     against numpy's stable sort; once more with the scan kernels on the same input."""
     import torch
     import radx_amd
