@@ -79,6 +79,7 @@ constexpr uint32_t kGroupBaseWords = kMaxGroups * 16;  // where the bases start
 // Up to this many groups every tile workgroup adds up the group sums itself (2 table rows per
 // team of 16 lanes) instead of waiting for the scanning workgroup's bases: one step less in the
 // chain, which counts when the whole launch is one round of workgroups.
+constexpr int kStaggerSleep = 32;  // x 64 cycles between the workgroups that share a CU in a launch's first round
 constexpr uint32_t kOneLevelGroups = 32;
 constexpr int kOneLevelIters = kOneLevelGroups / 16;
 
@@ -653,6 +654,18 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             run += w[i];
         }
         return;
+    }
+    // The workgroups that start a launch together on one CU would all load, then all rank, then
+    // all store: the memory system gets their loads in one burst and idles while they rank.  The
+    // dispatcher deals the first 256 workgroups one to each CU, the next 256 likewise, and so on,
+    // so workgroup b is the (b / 256)-th of its CU: it starts that many steps of kStaggerSleep x 64
+    // cycles late, which spreads the first round's phases for the whole launch (2^21..2^25 uint32
+    // keys: 2-5 % per sort; sleeping once the loads are issued gains nothing).  Speed only.
+    if (SCANLESS) {
+        constexpr uint32_t slots = HAS_V ? 4u : 5u;  // workgroups per CU in one round
+        const uint32_t slot_in_cu = (blockIdx.x - publishers) >> 8;
+        if (slot_in_cu < slots)
+            for (uint32_t k = 0; k < slot_in_cu; ++k) __builtin_amdgcn_s_sleep(kStaggerSleep);
     }
     const uint32_t g = tile_of_workgroup<xcd_block<K, HAS_V>()>(blockIdx.x - publishers, num_tiles);
     const uint32_t base = g * TILE;
