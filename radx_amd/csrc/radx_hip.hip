@@ -964,13 +964,21 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
 #pragma unroll
     for (int q = 0; q < 4; ++q) read_base[q] = rank_slot<sizeof(K)>(q * kBlock + tid);
     uint32_t where[HAS_V ? NIT : 1];
+    // FUSE: the width of the next digit and the constant 1 the counters are bumped by, each held in a
+    // register (opaque to the compiler, which otherwise re-creates both from scalars for every key)
+    uint32_t next_width = __builtin_popcount(next_mask), one = 1u;
+    if (FUSE && sizeof(K) == 4) asm volatile("" : "+v"(next_width), "+v"(one));
     auto emit = [&](int m0, bool guarded, int restore) {
         K k[kGroup];
         uint4 w[kGroup];
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) k[j] = skeys[read_base[(m0 + j) & 3] + ((m0 + j) >> 2) * (4 * kBlock)];
+        uint32_t d16[kGroup];  // 16 x digit: the byte offset into where_s and the high part of the counter slot
 #pragma unroll
-        for (int j = 0; j < kGroup; ++j) w[j] = where_s[digit_of<K>(k[j], bit, mask)];
+        for (int j = 0; j < kGroup; ++j) {
+            d16[j] = digit_of<K>(k[j], bit, mask) << 4;
+            w[j] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(where_s) + d16[j]);
+        }
         uint32_t second_bits = 0;  // bit j: key j of the group lands in its run's second destination tile
 #pragma unroll
         for (int j = 0; j < kGroup; ++j) {
@@ -986,10 +994,13 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             if (live) kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];  // last pass restores the key's own bits
 #endif
             if (FUSE) {
-                const uint32_t slot = (digit_of<K>(k[j], bit, mask) << 4) | digit_of<K>(k[j], next_bit, next_mask);
+                const uint32_t next_digit = sizeof(K) == 4
+                    ? __builtin_amdgcn_ubfe(static_cast<uint32_t>(k[j]), static_cast<uint32_t>(next_bit), next_width)
+                    : digit_of<K>(k[j], next_bit, next_mask);
+                const uint32_t slot = d16[j] | next_digit;
                 const bool in_first = at <= w[j].y;
                 if (live && in_first)
-                    __hip_atomic_fetch_add(&ctr[slot * kNextCols + col], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    __hip_atomic_fetch_add(&ctr[slot * kNextCols + col], one, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 second_bits |= (live && !in_first ? 1u : 0u) << j;
             }
         }
