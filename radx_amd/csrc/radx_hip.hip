@@ -816,7 +816,15 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
         if (PACK) rank[i / 2] = (i & 1) ? rank[i / 2] | (r << 16) : r;
         else rank[i] = r;
     }
-    if (SCANLESS) {
+    // SCANLESS: the tile's 16 output bases.  await_words: wait (with a bound) for the published
+    // words and reduce the group sums to one partial pair per wave; take_bases, one barrier
+    // later: wave 0 combines them (or, a word having failed to show up, every wave sums the table
+    // first).  The bases are not needed before the keys leave for global memory, so where the
+    // slot layout does not depend on them (!ALIGNED) both steps come after the block-wide scan:
+    // the workgroups that start a launch look for their words about when they are published,
+    // and every step the look moves back saves some of them a second look.
+    constexpr bool LATE_BASES = SCANLESS && !ALIGNED;
+    auto await_words = [&]() {
         if (one_level || wave == 0u) {
             for (int looks = 1;; ++looks) {
                 uint32_t there = base_word & prefix_word;
@@ -844,9 +852,8 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             part_s[wave * 2 * kRadices + lane] = tot;
             part_s[wave * 2 * kRadices + kRadices + lane] = bef;
         }
-    }
-    __syncthreads();
-    if (SCANLESS) {
+    };
+    auto take_bases = [&]() {
         if (self_sum_s) {  // uniform.  Never taken in practice: the column sums straight from the table.
             uint32_t tot = 0, bef = 0;
             for (uint32_t r = team; r < num_tiles; r += 16u) {
@@ -888,7 +895,10 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             if (g == 0u && lane == 0u && (one_level || sf.publish == 0)) sf.digit_starts[kRadices] = n;
             if (ALIGNED) place_runs();  // read after the next barrier
         }
-    }
+    };
+    if (SCANLESS && !LATE_BASES) await_words();
+    __syncthreads();
+    if (SCANLESS && !LATE_BASES) take_bases();
 
     // 3. block-wide exclusive scan, thread t owning words 8t..8t+7 of the row-major counter array.
     {
@@ -917,7 +927,9 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
         *reinterpret_cast<uint4*>(&ctr[tid * 8u]) = make_uint4(o[0], o[1], o[2], o[3]);
         *reinterpret_cast<uint4*>(&ctr[tid * 8u + 4u]) = make_uint4(o[4], o[5], o[6], o[7]);
     }
+    if (LATE_BASES) await_words();
     __syncthreads();
+    if (LATE_BASES) take_bases();
 
     // 4. tile ranks; digit d's tile run starts at the counter of (d, thread 0).
 #pragma unroll

@@ -21,8 +21,8 @@ if vb:
     v = torch.empty(n, dtype=torch.int32, device=dev)
     vswap = torch.empty_like(v)
 s = radx_amd.Sorter(n, kb, vb)
-s.tune(bool(fuse))
 import os
+s.tune(bool(fuse), scan_kernels=os.environ.get('QB_SCAN_KERNELS', '0') == '1')  # QB_SCAN_KERNELS=1: no scan-free passes
 s.profile(os.environ.get('QB_PROFILE', '1') == '1')  # QB_PROFILE=0: no per-launch events (for kernel traces)
 passes = kb * 2
 totals, scatters = [], []
