@@ -79,6 +79,10 @@ constexpr uint32_t kGroupBaseWords = kMaxGroups * 16;  // where the bases start
 // Up to this many groups every tile workgroup adds up the group sums itself (2 table rows per
 // team of 16 lanes) instead of waiting for the scanning workgroup's bases: one step less in the
 // chain, which counts when the whole launch is one round of workgroups.
+// A scan-free pass that writes between these many bytes stores them nontemporally (see scatter_kernel, NT):
+// up to half of what the eight L2s hold together; 24 MiB is already 8 % slower that way, and
+// below 3 MiB there is too little to write back for it to matter (1-2 % the other way).
+constexpr uint64_t kNtStoreMinBytes = 3ull << 20, kNtStoreMaxBytes = 16ull << 20;
 constexpr int kStaggerSleep = 32;  // x 64 cycles between the workgroups that share a CU in a launch's first round
 constexpr uint32_t kOneLevelGroups = 32;
 constexpr int kOneLevelIters = kOneLevelGroups / 16;
@@ -504,7 +508,13 @@ struct ScanFreeTables {
 // scan-free variant would take 98 without the bound (no spills with it).
 template <typename K, bool HAS_V> constexpr int scatter_min_waves() { return sizeof(K) == 4 && !HAS_V ? 5 : 1; }
 
-template <typename K, bool HAS_V, bool FUSE, bool SCANLESS>
+// NT: keys and payloads leave with nontemporal stores, which go to memory as they are issued.
+// With ordinary stores a launch whose output fits the L2s ends with all of it still dirty there,
+// and the write-back at the end of the kernel runs with nothing to overlap it (2^21 uint32 keys:
+// 96 -> 82 us per sort; 2^21 uint32 keys + payloads: 134 -> 96 us).  Larger outputs are evicted
+// as the kernel runs and want the L2 to merge the partial lines two tiles' runs share (2^25 keys:
+// 23 % slower with NT), so the host picks NT by the bytes a pass writes.
+template <typename K, bool HAS_V, bool FUSE, bool SCANLESS, bool NT = false>
 __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatter_kernel(
     const K* __restrict__ kin, K* __restrict__ kout, const uint32_t* __restrict__ vin,
     uint32_t* __restrict__ vout, uint32_t n, int bit, uint32_t mask,
@@ -1000,11 +1010,15 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             // slots hold (stale words) never passes this test, whatever digit it decodes to
             const bool live = ALIGNED ? (s - w[j].z) < w[j].w : (!guarded || s < valid);
             if (HAS_V) where[m0 + j] = ALIGNED && !live ? 0xffffffffu : at;
+            const K out_key = restore ? ordered_to_key<K>(k[j], restore) : k[j];  // the last pass restores the key's own bits
 #if defined(RADX_SAFE_STORES)  // development builds: a wrong output base shows up as a parity failure, not as a memory fault
-            if (live && at < n) kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];
+            if (live && at < n) {
 #else
-            if (live) kout[at] = restore ? ordered_to_key<K>(k[j], restore) : k[j];  // last pass restores the key's own bits
+            if (live) {
 #endif
+                if (NT) __builtin_nontemporal_store(out_key, &kout[at]);
+                else kout[at] = out_key;
+            }
             if (FUSE) {
                 const uint32_t next_digit = sizeof(K) == 4
                     ? __builtin_amdgcn_ubfe(static_cast<uint32_t>(k[j]), static_cast<uint32_t>(next_bit), next_width)
@@ -1079,7 +1093,11 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
 #else
             if (ALIGNED ? where[m] != 0xffffffffu : s < valid)
 #endif
-                vout[where[m]] = stage[rank_slot<4>((m & 3) * kBlock + tid) + (m >> 2) * (4 * kBlock)];
+            {
+                const uint32_t out_val = stage[rank_slot<4>((m & 3) * kBlock + tid) + (m >> 2) * (4 * kBlock)];
+                if (NT) __builtin_nontemporal_store(out_val, &vout[where[m]]);
+                else vout[where[m]] = out_val;
+            }
         }
     }
 }
@@ -1523,11 +1541,22 @@ int run_pass_typed(radx_hip_sorter* s, const PassArgs& a, hipStream_t stream) {
                                 s->prefix_words[after], s->digit_starts, s->publish};
         // the workgroups that publish the group sums come first, rounded up to the number of XCDs
         const uint32_t grid = g.num_tiles + ((group_count(g.num_tiles) + 1u + 7u) & ~7u);
+        // what a pass writes stays in the L2s to the end of the kernel if it fits: nontemporal stores then
+        const uint64_t pass_bytes = static_cast<uint64_t>(a.n) * (sizeof(K) + (HAS_V ? 4u : 0u));
+        const bool nt = pass_bytes >= kNtStoreMinBytes && pass_bytes <= kNtStoreMaxBytes;
         LaunchTimer t(s, 2, stream);
-        if (a.fuse_next)
+        if (a.fuse_next && nt)
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true, true, true>), dim3(grid), dim3(kBlock), hold_back, stream,
+                               kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
+                               a.next_bit, next_mask, next_counts, a.order_in, a.order_out, sf);
+        else if (a.fuse_next)
             hipLaunchKernelGGL((scatter_kernel<K, HAS_V, true, true>), dim3(grid), dim3(kBlock), hold_back, stream,
                                kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
                                a.next_bit, next_mask, next_counts, a.order_in, a.order_out, sf);
+        else if (nt)
+            hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false, true, true>), dim3(grid), dim3(kBlock), hold_back, stream,
+                               kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,
+                               0, 0u, static_cast<uint32_t*>(nullptr), a.order_in, a.order_out, sf);
         else
             hipLaunchKernelGGL((scatter_kernel<K, HAS_V, false, true>), dim3(grid), dim3(kBlock), hold_back, stream,
                                kin, kout, vin, vout, a.n, a.bit, mask, counts, s->offsets, s->group_sums, g.num_tiles,

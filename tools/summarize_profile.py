@@ -62,10 +62,10 @@ with open(os.path.join(root, "radx_amd", "csrc", "radx_hip.hip"), "rb") as f:
 out = {"tag": tag, "kernel_source_sha": kernel_sha, "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
        "`python3 bench.py --steps 1 --warmup 0 --no-cpu`, 2^30 uint32 keys",
        "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request); WRITE_SIZE exact"}
-# scatter_kernel<K, HAS_V, FUSE, SCANLESS>: the fused variant (7 of 8 passes) also counts the next
+# scatter_kernel<K, HAS_V, FUSE, SCANLESS, NT>: the fused variant (7 of 8 passes) also counts the next
 # pass's digits; 2^30 keys run with the scan kernels (SCANLESS = false)
-for key, needles in (("scatter", ("scatter_kernel<unsigned int, false, true, false>",)),
-                     ("scatter_last_pass", ("scatter_kernel<unsigned int, false, false, false>",)),
+for key, needles in (("scatter", ("scatter_kernel<unsigned int, false, true, false, false>",)),
+                     ("scatter_last_pass", ("scatter_kernel<unsigned int, false, false, false, false>",)),
                      ("hist", ("hist_kernel",))):
     rd, wr = corrected(*needles)
     if rd is not None:
