@@ -83,6 +83,7 @@ constexpr uint32_t kGroupBaseWords = kMaxGroups * 16;  // where the bases start
 // up to half of what the eight L2s hold together; 24 MiB is already 8 % slower that way, and
 // below 3 MiB there is too little to write back for it to matter (1-2 % the other way).
 constexpr uint64_t kNtStoreMinBytes = 3ull << 20, kNtStoreMaxBytes = 16ull << 20;
+constexpr uint32_t kSelfSumTiles = 32;  // scan-free tables of at most this many rows: no publishing, see scatter_kernel
 constexpr int kStaggerSleep = 32;  // x 64 cycles between the workgroups that share a CU in a launch's first round
 constexpr uint32_t kOneLevelGroups = 32;
 constexpr int kOneLevelIters = kOneLevelGroups / 16;
@@ -562,7 +563,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     const uint32_t publishers = SCANLESS ? (num_grps + 1u + 7u) & ~7u : 0u;
     if (SCANLESS && blockIdx.x < publishers) {
         const uint32_t b = blockIdx.x;
-        if (b > num_grps || sf.publish == 0) return;
+        if (b > num_grps || sf.publish == 0 || num_tiles <= kSelfSumTiles) return;
         if (b == num_grps && num_grps <= kOneLevelGroups) return;  // nobody reads the bases
         if (b < num_grps) {
             // One group of table rows.  Team t owns rows 4t .. 4t+3 (8t .. 8t+7 in groups of 128) of
@@ -693,7 +694,13 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     // Lanes 0..15 of wave 0: the tile's sums over its own group's rows in front of it.  One level:
     // every team's group sums as well (rows past the end re-read the last one and are masked when
     // summed).  Two levels: lanes 0..15 of wave 0 also read the output bases of the tile's group.
+    // A table of at most kSelfSumTiles rows is summed by every tile workgroup itself, with ordinary
+    // loads that hit the L2: shorter than the trip of a word through a publishing workgroup, its
+    // store and a load past the L2 (2^14..2^17 uint32 keys: 4-8 % per sort; from 64 rows on the
+    // published words win).
+    const bool self_mode = SCANLESS && num_tiles <= kSelfSumTiles;
     auto look_at_group_words = [&]() {
+        if (self_mode) return;
         if (tid < static_cast<uint32_t>(kRadices))
             prefix_word = __hip_atomic_load(&sf.prefix_words[static_cast<size_t>(g) * kRadices + tid], __ATOMIC_RELAXED,
                                             __HIP_MEMORY_SCOPE_AGENT);
@@ -714,7 +721,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     // and counting their keys.  Later workgroups find the words published and look right away.
     const bool late_look = blockIdx.x - publishers < 1024u;
     if (SCANLESS) {
-        if (tid == 0u) self_sum_s = 0u;
+        if (tid == 0u) self_sum_s = self_mode ? 1u : 0u;
         if (!late_look) look_at_group_words();
         if (ALIGNED && tid < static_cast<uint32_t>(kRadices)) run_len = counts[static_cast<size_t>(g) * kRadices + tid];
     } else if (tid < static_cast<uint32_t>(kRadices)) {
@@ -835,6 +842,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     // and every step the look moves back saves some of them a second look.
     constexpr bool LATE_BASES = SCANLESS && !ALIGNED;
     auto await_words = [&]() {
+        if (self_mode) return;
         if (one_level || wave == 0u) {
             for (int looks = 1;; ++looks) {
                 uint32_t there = base_word & prefix_word;
@@ -864,7 +872,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
         }
     };
     auto take_bases = [&]() {
-        if (self_sum_s) {  // uniform.  Never taken in practice: the column sums straight from the table.
+        if (self_sum_s) {  // uniform.  Small tables, or (never in practice) a word that failed to show up: the column sums straight from the table.
             uint32_t tot = 0, bef = 0;
             for (uint32_t r = team; r < num_tiles; r += 16u) {
                 const uint32_t w = counts[static_cast<size_t>(r) * kRadices + tcol];
