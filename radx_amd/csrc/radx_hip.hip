@@ -28,6 +28,9 @@
 //     of every scatter launch scan that pass's table and publish the results, and every tile
 //     workgroup picks up its 16 output bases from them (see scatter_kernel, SCANLESS).  One launch
 //     per pass instead of three.
+//     Such launches are short, so what surrounds the streaming counts: the workgroups that share
+//     a CU at the start of a launch begin a step apart instead of moving in lockstep, and a pass
+//     whose output would sit dirty in the L2s until the kernel ends stores it nontemporally.
 //   * Inputs of at most one tile are sorted by one launch of one workgroup: the keys stay in LDS
 //     through all passes (sort_tile_kernel).  Same digits, same stable rank, one launch instead
 //     of nine.
@@ -490,8 +493,8 @@ struct ScanFreeTables {
 // SCANLESS: no scan kernel runs for this pass; the scan is done by a few extra workgroups at the
 // front of the launch (their number rounded up to 8, which keeps the XCD of every tile workgroup).
 //   * Extra workgroup b < ceil(num_tiles / G) scans the 16 columns of table rows [G b, G b + G)
-//     of `counts` (G = 64 rows, 128 above 8192 tiles): it publishes, for every one of its tiles, the 16 sums of the group's rows in
-//     front of that tile, and the 16 sums over the whole group.
+//     of `counts` (G = 64 rows, 128 above 8192 tiles): it publishes, for every one of its tiles,
+//     the 16 sums of the group's rows in front of that tile, and the 16 sums over the whole group.
 //   * The next extra workgroup waits for those sums, scans them in (digit, group) order and
 //     publishes, per group, the 16 output bases of the group's first tile (and the 17 run starts).
 //   * The workgroup of tile g reads the 16 bases of its group and its own 16 in-group sums (two
@@ -499,8 +502,11 @@ struct ScanFreeTables {
 //     partitions[g][r], partition.comp:26) for readers of the tables.
 // A published word carries bit 31 (the values stay below 2^26) and is written with one agent-scope
 // store and read with agent-scope loads: value and "is there" travel in one word, so no fences.
-// Tile workgroups look for their bases only after their keys are loaded and counted in LDS; the
-// publishing workgroups have the lowest numbers, so they run first.  Nobody waits without a
+// Tile workgroups of the first round look for their words only after their keys are loaded and
+// counted in LDS (with 4-byte keys after the block-wide scan as well: the bases are not needed
+// before the keys leave); the publishing workgroups have the lowest numbers, so they run first.
+// A table of at most kSelfSumTiles rows is not published: every tile workgroup sums it itself.
+// Nobody waits without a
 // bound: whoever still misses a word after kMaxPolls looks sums the table itself — the scanning
 // workgroup its group sums, a tile workgroup its 16 bases — so no workgroup's completion depends
 // on another one's progress.  Tables rotate through three buffers: this pass's are read, the
