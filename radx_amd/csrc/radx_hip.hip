@@ -86,7 +86,7 @@ constexpr uint32_t kGroupBaseWords = kMaxGroups * 16;  // where the bases start
 // up to half of what the eight L2s hold together; 24 MiB is already 8 % slower that way, and
 // below 3 MiB there is too little to write back for it to matter (1-2 % the other way).
 constexpr uint64_t kNtStoreMinBytes = 3ull << 20, kNtStoreMaxBytes = 16ull << 20;
-constexpr uint32_t kSelfSumTiles = 32;  // scan-free tables of at most this many rows: no publishing, see scatter_kernel
+constexpr uint32_t kSelfSumTiles = 64;  // scan-free tables of at most this many rows: no publishing, see scatter_kernel
 constexpr int kStaggerSleep = 32;  // x 64 cycles between the workgroups that share a CU in a launch's first round
 constexpr uint32_t kOneLevelGroups = 32;
 constexpr int kOneLevelIters = kOneLevelGroups / 16;
@@ -702,7 +702,7 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     // summed).  Two levels: lanes 0..15 of wave 0 also read the output bases of the tile's group.
     // A table of at most kSelfSumTiles rows is summed by every tile workgroup itself, with ordinary
     // loads that hit the L2: shorter than the trip of a word through a publishing workgroup, its
-    // store and a load past the L2 (2^14..2^17 uint32 keys: 4-8 % per sort; from 64 rows on the
+    // store and a load past the L2 (2^14..2^18 uint32 keys: 4-8 % per sort; from 128 rows on the
     // published words win).
     const bool self_mode = SCANLESS && num_tiles <= kSelfSumTiles;
     auto look_at_group_words = [&]() {
@@ -880,10 +880,19 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
     auto take_bases = [&]() {
         if (self_sum_s) {  // uniform.  Small tables, or (never in practice) a word that failed to show up: the column sums straight from the table.
             uint32_t tot = 0, bef = 0;
-            for (uint32_t r = team; r < num_tiles; r += 16u) {
-                const uint32_t w = counts[static_cast<size_t>(r) * kRadices + tcol];
-                tot += w;
-                bef += r < g ? w : 0u;
+            // 8 rows per team in flight at a time: the loads hit the L2 and are independent
+            for (uint32_t r0 = team; r0 < num_tiles; r0 += 16u * 8u) {
+                uint32_t w[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t r = r0 + 16u * j;
+                    w[j] = r < num_tiles ? counts[static_cast<size_t>(r) * kRadices + tcol] : 0u;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    tot += w[j];
+                    bef += r0 + 16u * j < g ? w[j] : 0u;
+                }
             }
             tot += __shfl_xor(tot, 16, 64); bef += __shfl_xor(bef, 16, 64);
             tot += __shfl_xor(tot, 32, 64); bef += __shfl_xor(bef, 32, 64);
