@@ -861,20 +861,23 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             }
         }
         // One level: the group sums, every team's partial column sums, then the 4 teams of a wave.
-        uint32_t tot = 0, bef = 0;
-        if (one_level) {
+        // Two levels: the scanning workgroup has done all of that and there is nothing to add up;
+        // skipping the empty reduction is worth 2 % to 4-byte keys (2^24..2^26) and costs 8-byte
+        // keys 2-5 %, measured — hence by key size.
+        if (one_level || !LATE_BASES) {
+            uint32_t tot = 0, bef = 0;
 #pragma unroll
             for (int i = 0; i < kOneLevelIters; ++i) {
-                const uint32_t r = team + 16u * i, w = grp_word[i] & ~kGroupValid;
+                const uint32_t r = team + 16u * i, w = one_level ? grp_word[i] & ~kGroupValid : 0u;
                 tot += r < num_grps ? w : 0u;
                 bef += r < my_grp ? w : 0u;
             }
-        }
-        tot += __shfl_xor(tot, 16, 64); bef += __shfl_xor(bef, 16, 64);
-        tot += __shfl_xor(tot, 32, 64); bef += __shfl_xor(bef, 32, 64);
-        if (lane < static_cast<uint32_t>(kRadices)) {
-            part_s[wave * 2 * kRadices + lane] = tot;
-            part_s[wave * 2 * kRadices + kRadices + lane] = bef;
+            tot += __shfl_xor(tot, 16, 64); bef += __shfl_xor(bef, 16, 64);
+            tot += __shfl_xor(tot, 32, 64); bef += __shfl_xor(bef, 32, 64);
+            if (lane < static_cast<uint32_t>(kRadices)) {
+                part_s[wave * 2 * kRadices + lane] = tot;
+                part_s[wave * 2 * kRadices + kRadices + lane] = bef;
+            }
         }
     };
     auto take_bases = [&]() {
@@ -903,18 +906,22 @@ __global__ __launch_bounds__(kBlock, (scatter_min_waves<K, HAS_V>())) void scatt
             __syncthreads();
         }
         if (wave == 0u) {
-            uint32_t tot = 0, bef = 0;
-            if (lane < static_cast<uint32_t>(kRadices)) {
+            if (one_level || self_sum_s || !LATE_BASES) {  // uniform
+                uint32_t tot = 0, bef = 0;
+                if (lane < static_cast<uint32_t>(kRadices)) {
 #pragma unroll
-                for (int w = 0; w < kBlock / 64; ++w) {
-                    tot += part_s[w * 2 * kRadices + lane];
-                    bef += part_s[w * 2 * kRadices + kRadices + lane];
+                    for (int w = 0; w < kBlock / 64; ++w) {
+                        tot += part_s[w * 2 * kRadices + lane];
+                        bef += part_s[w * 2 * kRadices + kRadices + lane];
+                    }
                 }
+                // the digit starts from the totals (lanes past 15 add 0), then what lies in front of the tile
+                const uint32_t scanned = wave_inclusive_scan(tot) - tot;
+                const uint32_t start = (one_level || self_sum_s) ? scanned : base_word & ~kGroupValid;
+                run_base = start + bef + (self_sum_s ? 0u : prefix_word & ~kGroupValid);
+            } else {
+                run_base = (base_word & ~kGroupValid) + (prefix_word & ~kGroupValid);  // the group's bases + the tile's place in its group
             }
-            // the group's bases, or (having summed the table here) the digit starts: lanes past 15 add 0
-            const uint32_t scanned = wave_inclusive_scan(tot) - tot;
-            const uint32_t start = (one_level || self_sum_s) ? scanned : base_word & ~kGroupValid;
-            run_base = start + bef + (self_sum_s ? 0u : prefix_word & ~kGroupValid);
             if (lane < static_cast<uint32_t>(kRadices)) {
                 offsets[static_cast<size_t>(g) * kRadices + lane] = run_base;
                 sf.zero_counts[static_cast<size_t>(g) * kRadices + lane] = 0u;
