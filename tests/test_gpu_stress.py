@@ -98,3 +98,35 @@ def test_scan_free_sizes_with_many_row_groups(device, key_bytes, with_vals, tile
             assert np.array_equal(to_host(v), vals[order].astype(np.uint32)), "scan kernels: %s" % scan_kernels
         del k, swap, v, vswap
     s.close()
+
+
+@pytest.mark.parametrize("key_bytes,with_vals,n,dist", [
+    (4, False, 1_500_007, "uniform"), (4, True, 1_000_003, "heavy"), (8, False, 1_048_576, "few_distinct"),
+    (8, True, 900_001, "heavy"), (4, True, 393_216, "sorted"), (4, False, 4_194_304, "skewed")])
+def test_sizes_whose_passes_store_nontemporally(device, key_bytes, with_vals, n, dist):
+    """Passes that write between 3 and 16 MiB leave with nontemporal stores (and a staggered first
+    round): every shape at such a size, the two ends of the range included, ties with payloads
+    (stability), a signed descending order on the way — against numpy's stable sort, and once
+    more with the scan kernels (ordinary stores) on the same input."""
+    import torch
+    import radx_amd
+    rng = np.random.default_rng(n)
+    assert 3 << 20 <= n * (key_bytes + (4 if with_vals else 0)) <= 16 << 20
+    keys = skewed_keys(rng, n, key_bytes) if dist == "heavy" else make_keys(dist, n, key_bytes, seed=n % 1000)
+    vals = np.arange(n, dtype=np.uint32)
+    s = radx_amd.Sorter(n, key_bytes, 4 if with_vals else 0)
+    for kind, descending in (("unsigned", False), ("signed", True)):
+        order = np.argsort(ordered_image(keys, kind, descending), kind="stable")
+        s.set_key_order(kind, descending)
+        for scan_kernels in (False, True):
+            s.tune(True, scan_kernels=scan_kernels)
+            k = to_dev(keys, device)
+            swap = torch.empty_like(k)
+            v = to_dev(vals, device) if with_vals else None
+            vswap = torch.empty_like(v) if with_vals else None
+            s.sort(k, swap, v, vswap)
+            torch.cuda.synchronize()
+            assert np.array_equal(to_host(k, key_bytes), keys[order]), (kind, descending, scan_kernels)
+            if with_vals:
+                assert np.array_equal(to_host(v), vals[order]), (kind, descending, scan_kernels)
+    s.close()
